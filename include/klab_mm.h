@@ -1,0 +1,163 @@
+/* klab_mm.h -- C ABI of the MI355X-native Swin-V2 -> T5 caption-training hot path.
+ *
+ * The reference (Da-Tsuchi/KLab_MultiModalModel) has no FFI of its own: its hot path is the
+ * Python call `MyModel.forward` + autograd backward (ref/models/model.py:19-26, ref/train.py:58-62),
+ * whose arithmetic runs inside `transformers` (HF/swinv2, HF/t5; see SURVEY.md for the prefixes).
+ * This header is the boundary a maintainer would bind instead (last row): plain
+ * pointers and sizes, no torch types.  Conventions for EVERY entry point:
+ *   - all buffers are caller-owned device allocations; nothing is allocated, freed or retained
+ *     (the engine object is the one exception: it owns only host-side plans);
+ *   - every call is stream-ordered on the `hipStream_t` passed as `void* stream`, never
+ *     synchronises and never throws; it returns 0, a positive `hipError_t`, or a negative KLAB_ERR_*;
+ *   - `dtype` is the storage type of GEMM operands / activations: KLAB_F32 (parity mode, exact f32
+ *     MFMA) or KLAB_BF16 (bf16 operands, fp32 accumulation, fp32 residual stream and statistics);
+ *   - dropout masks are a pure function of (*seed_dev, tag, element index) so that backward
+ *     regenerates them; `seed_dev` points to ONE uint32 in device memory (graph-replay friendly).
+ */
+#ifndef KLAB_MM_H
+#define KLAB_MM_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KLAB_OK 0
+#define KLAB_ERR_UNSUPPORTED (-2)
+#define KLAB_ERR_BADARG (-3)
+
+#define KLAB_F32 0
+#define KLAB_BF16 1
+
+#define KLAB_ACT_NONE 0
+#define KLAB_ACT_RELU 1 /* T5 DenseReluDense, HF/t5:83-94 */
+#define KLAB_ACT_GELU 2 /* erf GELU, Swin-V2 MLP, HF/swinv2:539-548 */
+
+#define KLAB_AUX_NONE 0
+#define KLAB_AUX_NONZERO 1 /* x = aux!=0 ? x*aux_scale : 0   (backward of relu+dropout) */
+#define KLAB_AUX_DGELU 2   /* x *= gelu'(aux)                (backward of erf GELU)    */
+
+int klab_version(void);
+
+/* ---- dense contraction (replaces every nn.Linear / Conv2d-as-GEMM of HF/t5 and HF/swinv2 and
+ *      their autograd dgrad/wgrad; SURVEY §2.4 K1,K5,K6,K11-K14) -------------------------------
+ * C[M,N] = epilogue(alpha * sum_k A(m,k) * B(n,k)).
+ * a_kmajor=1: A(m,k) = A[m*lda + k]   (x[M,K] of a Linear forward)
+ * a_kmajor=0: A(m,k) = A[k*lda + m]   (contraction over the slow dimension: wgrad)
+ * same for B (b_kmajor=1 is a torch Linear weight W[N,K]).                                      */
+typedef struct klab_gemm_args {
+  int M, N, K;
+  int dtype;   /* operand dtype */
+  const void* A; long lda; int a_kmajor;
+  const void* B; long ldb; int b_kmajor;
+  void* C; long ldc; int c_dtype; /* KLAB_F32 or == dtype */
+  int accumulate;                 /* C += result */
+  float alpha; const float* alpha_dev; /* effective alpha = alpha * (*alpha_dev if non-null) */
+  const float* bias;              /* [N] f32 or NULL */
+  int act;
+  const void* aux; long ldaux; int aux_mode; float aux_scale; /* aux: [M,N] in `dtype` */
+  const void* residual; long ldr; int r_dtype;                /* added last */
+  float drop_p; const uint32_t* seed_dev; uint32_t drop_tag;  /* dropout before the residual */
+} klab_gemm_args;
+int klab_gemm(const klab_gemm_args* args, void* stream);
+
+/* ---- T5 RMS-norm (T5LayerNorm, HF/t5:59-72) ------------------------------------------------
+ * y = drop(x * rsqrt(mean(x^2)+eps) * w); x is the f32 residual stream [rows,d]; y (dtype y_dtype)
+ * and/or y_f32 are written at row (row/grp)*grp_stride + row%grp + off when grp>0 (this is how the
+ * frozen language encoder writes its output straight into the concatenated encoder input,
+ * ref/models/model.py:23).  rstd[rows] is saved for backward (may be NULL).                     */
+int klab_rmsnorm_fwd(const float* x, const float* w, void* y, int y_dtype, float* y_f32, float* rstd, int rows, int d,
+                     float eps, int grp, int grp_stride, int off, float drop_p, const uint32_t* seed_dev,
+                     uint32_t tag, void* stream);
+/* backward: dx = dres + rmsnorm'(dy * dropmask_y); dw += ...; dxt = dtype(dx * dropmask_prev)
+ * (dxt is the gradient of the previous sub-layer's GEMM output: residual add + dropout of
+ * HF/t5:400,141).  dy is indexed through the same row remap as y.                              */
+int klab_rmsnorm_bwd(const float* dy, const float* x, const float* w, const float* rstd, const float* dres, float* dx,
+                     void* dxt, int dxt_dtype, float* dw, int rows, int d, int grp, int grp_stride, int off,
+                     float p_y, uint32_t tag_y, float p_prev, uint32_t tag_prev, const uint32_t* seed_dev,
+                     void* stream);
+
+/* ---- Swin-V2 LayerNorm, res-post-norm form (HF/swinv2:697-702; also :242, :354, :953) --------
+ * out = drop(shortcut + LN(y)*gamma + beta)  (f32, remapped rows) and/or outt (dtype copy).     */
+int klab_layernorm_fwd(const void* y, int y_dtype, const float* gamma, const float* beta, const float* shortcut,
+                       float* out, void* outt, int outt_dtype, float* mean, float* rstd, int rows, int C, float eps,
+                       int grp, int grp_stride, int off, float drop_p, const uint32_t* seed_dev, uint32_t tag,
+                       void* stream);
+int klab_layernorm_bwd(const float* dout, const void* y, int y_dtype, const float* gamma, const float* mean,
+                       const float* rstd, void* dy, float* dgamma, float* dbeta, int rows, int C, int grp,
+                       int grp_stride, int off, float drop_p, const uint32_t* seed_dev, uint32_t tag, void* stream);
+
+/* ---- T5 attention core (HF/t5:144-173 as called from :281-369) ------------------------------
+ * S = Q K^T (unscaled, HF/t5:196-197) + bias[h,Lq,Lk] (+ causal); P = softmax(S); ctx = drop(P) V.
+ * q/k/v/ctx/dq/dk/dv are [B*L, ld] matrices in `dtype`, head h at column h*dk (no transposes).
+ * lse[B,H,Lq] (f32) is written by fwd and read by bwd; dbias[h,Lq,Lk] (f32) is ACCUMULATED by
+ * bwd (position-bias gradient, shared by all layers: HF/t5:739-742) and may be NULL.            */
+typedef struct klab_attn_args {
+  int dtype;
+  const void* q; long ldq;
+  const void* k; long ldk;
+  const void* v; long ldv;
+  const float* bias; int causal;
+  void* ctx; long ldo;
+  float* lse;
+  int B, H, Lq, Lk, dk;
+  float drop_p; const uint32_t* seed_dev; uint32_t drop_tag;
+  /* backward only */
+  const void* dctx; long lddo;
+  void* dq; long lddq;
+  void* dk_out; long lddk;
+  void* dv; long lddv;
+  float* dbias;
+} klab_attn_args;
+int klab_t5_attn_fwd(const klab_attn_args* a, void* stream);
+int klab_t5_attn_bwd(const klab_attn_args* a, void* stream);
+
+/* ---- Swin-V2 shifted-window cosine attention (HF/swinv2:389-455 + roll/partition/mask/reverse of
+ * :652-705, :146-166, :620-643) -- one call per block.  qkv [B*R*R, 3C], ctx [B*R*R, C] (`dtype`),
+ * bias [H, w*w, w*w] f32 (= 16*sigmoid(CPB), klab_swin_cpb_bias), logit_scale [H] f32 (raw param),
+ * lse [B*nW*H*w*w] f32 (fwd out, optional; bwd in).  bwd writes dqkv and accumulates dbias /
+ * dlogit_scale.  R % w must be 0 (the padded-window path is out of scope).                      */
+typedef struct klab_swin_attn_args {
+  int dtype;
+  const void* qkv; void* ctx; const float* bias; const float* logit_scale; float* lse;
+  int B, R, w, shift, H, C;
+  const void* dctx; void* dqkv; float* dbias; float* dlogit_scale;
+} klab_swin_attn_args;
+int klab_swin_attn_fwd(const klab_swin_attn_args* a, void* stream);
+int klab_swin_attn_bwd(const klab_swin_attn_args* a, void* stream);
+/* continuous position bias (HF/swinv2:376-378,418-428): coords [(2w-1)^2,2], index [n*n] are the
+ * input-independent buffers of HF/swinv2:457-492; table [(2w-1)^2,H] and hidden [(2w-1)^2,512]
+ * (optional, for backward) are scratch/outputs.                                                 */
+int klab_swin_cpb_bias(const float* coords, const int* index, const float* w0, const float* b0, const float* w2,
+                       float* table, float* hidden, float* bias, int ntab, int n, int heads, int nhidden, void* stream);
+
+/* ---- glue --------------------------------------------------------------------------------- */
+/* multi-tensor f32 -> dtype cast into one arena; desc_dev: device array of
+ * {const float* src; long dst_off; long n4_prefix} (prefix sums of element counts / 4)           */
+int klab_cast_pack(const void* desc_dev, int ndesc, long total4, void* dst, int dtype, void* stream);
+/* embedding gather with optional T5 _shift_right (HF/t5:618-637) and input dropout (HF/t5:725)  */
+int klab_embed_fwd(const long long* ids, int shift_right, int L, int start_id, int pad_id, const float* table, int vocab,
+                   float* out, int rows, int d, float drop_p, const uint32_t* seed_dev, uint32_t tag, int* err_flag,
+                   void* stream);
+int klab_embed_bwd(const long long* ids, int shift_right, int L, int start_id, int pad_id, const float* dh, float* dtable,
+                   int vocab, int rows, int d, float drop_p, const uint32_t* seed_dev, uint32_t tag, void* stream);
+/* relative position bias gather / scatter (HF/t5:264-279); bucket[Lq*Lk] int32 from the host     */
+int klab_relbias_fwd(const float* table, const int* bucket, float* bias, int heads, int Lq, int Lk, void* stream);
+int klab_relbias_bwd(const float* dbias, const int* bucket, float* dtable, int heads, int Lq, int Lk, int nbuckets,
+                     void* stream);
+/* cross-entropy over logits [rows, V] (HF/t5:1050-1054); with write_grad the logits are replaced in
+ * place by d loss / d logits = (softmax - onehot) / n_valid.  loss_row [rows], inv_n [1], loss [1]. */
+int klab_ce_fwd(void* logits, long ld, int dtype, const long long* labels, int rows, int V, float* inv_n, float* loss_row,
+                float* loss, int write_grad, void* stream);
+int klab_im2col_patch(const float* pixels, void* out, int dtype, int B, int Cin, int Himg, int P, void* stream);
+int klab_merge_gather(const float* x, void* out, int dtype, int B, int R, int C, void* stream);
+int klab_merge_scatter(const float* dmerged, float* dx, int B, int R, int C, void* stream);
+int klab_colsum(const void* dy, long ld, int dtype, int M, int N, float* out, void* stream);
+int klab_convert(const float* x, void* y, int dtype, long n, float scale, void* stream);
+int klab_add_f32(float* y, const float* x, long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KLAB_MM_H */

@@ -1,0 +1,122 @@
+"""ctypes binding of libklab_mm.so (the C ABI declared in include/klab_mm.h).
+
+The product path fails loudly when the HIP library is missing: there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libklab_mm.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+AUX_NONE, AUX_NONZERO, AUX_DGELU = 0, 1, 2
+ERR_UNSUPPORTED, ERR_BADARG = -2, -3
+
+vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint32
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("M", i32), ("N", i32), ("K", i32), ("dtype", i32),
+                ("A", vp), ("lda", i64), ("a_kmajor", i32),
+                ("B", vp), ("ldb", i64), ("b_kmajor", i32),
+                ("C", vp), ("ldc", i64), ("c_dtype", i32), ("accumulate", i32),
+                ("alpha", f32), ("alpha_dev", vp), ("bias", vp), ("act", i32),
+                ("aux", vp), ("ldaux", i64), ("aux_mode", i32), ("aux_scale", f32),
+                ("residual", vp), ("ldr", i64), ("r_dtype", i32),
+                ("drop_p", f32), ("seed_dev", vp), ("drop_tag", u32)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("dtype", i32), ("q", vp), ("ldq", i64), ("k", vp), ("ldk", i64), ("v", vp), ("ldv", i64),
+                ("bias", vp), ("causal", i32), ("ctx", vp), ("ldo", i64), ("lse", vp),
+                ("B", i32), ("H", i32), ("Lq", i32), ("Lk", i32), ("dk", i32),
+                ("drop_p", f32), ("seed_dev", vp), ("drop_tag", u32),
+                ("dctx", vp), ("lddo", i64), ("dq", vp), ("lddq", i64), ("dk_out", vp), ("lddk", i64),
+                ("dv", vp), ("lddv", i64), ("dbias", vp)]
+
+
+class SwinAttnArgs(C.Structure):
+    _fields_ = [("dtype", i32), ("qkv", vp), ("ctx", vp), ("bias", vp), ("logit_scale", vp), ("lse", vp),
+                ("B", i32), ("R", i32), ("w", i32), ("shift", i32), ("H", i32), ("C", i32),
+                ("dctx", vp), ("dqkv", vp), ("dbias", vp), ("dlogit_scale", vp)]
+
+
+# every exported entry point of include/klab_mm.h: name -> argtypes (restype is always int)
+SIGNATURES = {
+    "klab_version": [],
+    "klab_gemm": [C.POINTER(GemmArgs), vp],
+    "klab_rmsnorm_fwd": [vp, vp, vp, i32, vp, vp, i32, i32, f32, i32, i32, i32, f32, vp, u32, vp],
+    "klab_rmsnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, f32, u32, f32, u32, vp, vp],
+    "klab_layernorm_fwd": [vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, f32, i32, i32, i32, f32, vp, u32, vp],
+    "klab_layernorm_bwd": [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, u32, vp],
+    "klab_t5_attn_fwd": [C.POINTER(AttnArgs), vp],
+    "klab_t5_attn_bwd": [C.POINTER(AttnArgs), vp],
+    "klab_swin_attn_fwd": [C.POINTER(SwinAttnArgs), vp],
+    "klab_swin_attn_bwd": [C.POINTER(SwinAttnArgs), vp],
+    "klab_swin_cpb_bias": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "klab_cast_pack": [vp, i32, i64, vp, i32, vp],
+    "klab_embed_fwd": [vp, i32, i32, i32, i32, vp, i32, vp, i32, i32, f32, vp, u32, vp, vp],
+    "klab_embed_bwd": [vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, f32, vp, u32, vp],
+    "klab_relbias_fwd": [vp, vp, vp, i32, i32, i32, vp],
+    "klab_relbias_bwd": [vp, vp, vp, i32, i32, i32, i32, vp],
+    "klab_ce_fwd": [vp, i64, i32, vp, i32, i32, vp, vp, vp, i32, vp],
+    "klab_im2col_patch": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "klab_merge_gather": [vp, vp, i32, i32, i32, i32, vp],
+    "klab_merge_scatter": [vp, vp, i32, i32, i32, vp],
+    "klab_colsum": [vp, i64, i32, i32, i32, vp, vp],
+    "klab_convert": [vp, vp, i32, i64, f32, vp],
+    "klab_add_f32": [vp, vp, i64, vp],
+}
+
+_lib = None
+
+
+class KlabError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the HIP library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KlabError(f"{LIB_PATH} is missing: run `python -m klab_multimodalmodel_amd.build` "
+                        "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argt in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.argtypes = argt
+        fn.restype = i32
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc == 0:
+        return
+    if rc == ERR_UNSUPPORTED:
+        raise NotImplementedError(f"klab: unsupported shape/alignment in {what}")
+    if rc == ERR_BADARG:
+        raise ValueError(f"klab: bad argument to {what}")
+    raise KlabError(f"klab: {what} failed with hipError {rc}")
+
+
+def ptr(t):
+    """device pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def dtype_code(torch_dtype):
+    import torch
+    if torch_dtype == torch.float32:
+        return F32
+    if torch_dtype == torch.bfloat16:
+        return BF16
+    raise ValueError(f"unsupported dtype {torch_dtype}")
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,317 @@
+// T5 attention core (HF/t5:144-173 eager_attention_forward as called from HF/t5:281-369):
+//   S = Q K^T * 1.0 + position_bias (+ causal mask in the decoder, HF/t5:697-711)
+//   P = softmax(S);  Pd = dropout(P);  ctx = Pd V
+// The q/k/v/o projections are klab_gemm calls; this file is the part between them, forward and
+// backward, reading Q/K/V in place from the fused projection buffers (head h at column h*dk) and
+// writing ctx / dQ / dK / dV in the same layouts, so no transpose or head split/merge is ever
+// materialised.  K and V of one (batch, head) are staged in LDS once per workgroup; softmax
+// statistics are fp32 with wave-shuffle reductions; backward recomputes P from the saved
+// log-sum-exp (no [B,h,Lq,Lk] tensor is stored) and regenerates the dropout mask from the counter
+// RNG.  The relative-position-bias gradient is accumulated with f32 atomics into [h,Lq,Lk].
+// Round-1 form: dot products on the vector ALU in fp32 (sequence lengths here are 58-160; the
+// contraction is 1.4 % of the step's FLOPs); an MFMA form is the planned replacement.
+#include <math.h>
+
+#include "common.h"
+#include "klab_mm.h"
+
+namespace klab {
+
+struct AttnP {
+  const void* q; long ldq;
+  const void* k; long ldk;
+  const void* v; long ldv;
+  const float* bias;  // [H,Lq,Lk] or null
+  int causal;
+  void* ctx; long ldo;
+  float* lse;         // [B,H,Lq]
+  int B, H, Lq, Lk, dk;
+  float p; const uint32_t* seed; uint32_t tag;
+  // backward only
+  const void* dctx; long lddo;
+  void* dq; long lddq;
+  void* dkk; long lddk;
+  void* dv; long lddv;
+  float* dbias;
+};
+
+constexpr int TQ = 16;
+
+template <typename T> __device__ __forceinline__ void load_vec_f32(const T* p, float* o);
+template <> __device__ __forceinline__ void load_vec_f32<float>(const float* p, float* o) {
+  f32x4 v = *reinterpret_cast<const f32x4*>(p);
+  o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+}
+template <> __device__ __forceinline__ void load_vec_f32<bf16_t>(const bf16_t* p, float* o) {
+  bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+}
+
+template <typename T>
+__device__ __forceinline__ void stage_kv(const T* __restrict__ g, long ld, int b, int h, int Lk, int dk, T* lds, int stride) {
+  constexpr int VEC = Vec16<T>::N;
+  using V = typename Vec16<T>::type;
+  const int cpr = dk / VEC;
+  for (int ch = threadIdx.x; ch < Lk * cpr; ch += blockDim.x) {
+    const int j = ch / cpr, c = (ch % cpr) * VEC;
+    *reinterpret_cast<V*>(lds + j * stride + c) = *reinterpret_cast<const V*>(g + ((long)b * Lk + j) * ld + (long)h * dk + c);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void t5_attn_fwd_kernel(AttnP p) {
+  constexpr int VEC = Vec16<T>::N;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int Lk = p.Lk, dk = p.dk, Lq = p.Lq;
+  const int kst = dk + VEC;  // padded LDS row (elements)
+  T* Ks = reinterpret_cast<T*>(smem);
+  T* Vs = Ks + (size_t)Lk * kst;
+  float* Qs = reinterpret_cast<float*>(Vs + (size_t)Lk * kst);
+  float* Ps = Qs + TQ * dk;
+  const int pst = Lk + 1;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+  const int q0 = blockIdx.x * TQ;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  stage_kv<T>(reinterpret_cast<const T*>(p.k), p.ldk, b, h, Lk, dk, Ks, kst);
+  stage_kv<T>(reinterpret_cast<const T*>(p.v), p.ldv, b, h, Lk, dk, Vs, kst);
+  const T* qg = reinterpret_cast<const T*>(p.q);
+  for (int idx = tid; idx < TQ * dk; idx += 256) {
+    const int i = idx / dk, c = idx % dk, qi = q0 + i;
+    Qs[idx] = qi < Lq ? to_f32(qg[((long)b * Lq + qi) * p.ldq + (long)h * dk + c]) : 0.f;
+  }
+  __syncthreads();
+
+  for (int idx = tid; idx < TQ * Lk; idx += 256) {
+    const int i = idx / Lk, j = idx % Lk, qi = q0 + i;
+    float s = -INFINITY;
+    if (qi < Lq && !(p.causal && j > qi)) {
+      s = 0.f;
+      const T* kr = Ks + j * kst;
+      const float* qr = Qs + i * dk;
+      for (int c = 0; c < dk; c += VEC) {
+        float kv[VEC];
+        load_vec_f32<T>(kr + c, kv);
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) s += qr[c + u] * kv[u];
+      }
+      if (p.bias) s += p.bias[((long)h * Lq + qi) * Lk + j];
+    }
+    Ps[i * pst + j] = s;
+  }
+  __syncthreads();
+
+  const DropCtx dc = make_drop(p.seed, p.tag, p.p);
+  for (int i = wave; i < TQ; i += 4) {
+    const int qi = q0 + i;
+    if (qi >= Lq) continue;
+    float m = -INFINITY;
+    for (int j = lane; j < Lk; j += 64) m = fmaxf(m, Ps[i * pst + j]);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int j = lane; j < Lk; j += 64) sum += __expf(Ps[i * pst + j] - m);
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    if (lane == 0 && p.lse) p.lse[((long)b * p.H + h) * Lq + qi] = m + __logf(sum);
+    const uint64_t base = (((uint64_t)b * p.H + h) * Lq + qi) * (uint64_t)Lk;
+    for (int j = lane; j < Lk; j += 64) Ps[i * pst + j] = __expf(Ps[i * pst + j] - m) * inv * drop_mult(dc, base + j);
+  }
+  __syncthreads();
+
+  T* og = reinterpret_cast<T*>(p.ctx);
+  for (int idx = tid; idx < TQ * dk; idx += 256) {
+    const int i = idx / dk, c = idx % dk, qi = q0 + i;
+    if (qi >= Lq) continue;
+    float o = 0.f;
+    const float* pr = Ps + i * pst;
+    for (int j = 0; j < Lk; ++j) o += pr[j] * to_f32(Vs[j * kst + c]);
+    og[((long)b * Lq + qi) * p.ldo + (long)h * dk + c] = from_f32<T>(o);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void t5_attn_bwd_kernel(AttnP p) {
+  constexpr int VEC = Vec16<T>::N;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int Lk = p.Lk, dk = p.dk, Lq = p.Lq;
+  const int kst = dk + VEC, pst = Lk + 1;
+  T* Ks = reinterpret_cast<T*>(smem);
+  T* Vs = Ks + (size_t)Lk * kst;
+  float* dKs = reinterpret_cast<float*>(Vs + (size_t)Lk * kst);
+  float* dVs = dKs + (size_t)Lk * dk;
+  float* Qs = dVs + (size_t)Lk * dk;
+  float* dOs = Qs + TQ * dk;
+  float* Ps = dOs + TQ * dk;
+  float* dSs = Ps + TQ * pst;
+  float* delta = dSs + TQ * pst;
+  float* lses = delta + TQ;
+  const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const DropCtx dc = make_drop(p.seed, p.tag, p.p);
+
+  stage_kv<T>(reinterpret_cast<const T*>(p.k), p.ldk, b, h, Lk, dk, Ks, kst);
+  stage_kv<T>(reinterpret_cast<const T*>(p.v), p.ldv, b, h, Lk, dk, Vs, kst);
+  for (int idx = tid; idx < Lk * dk; idx += 256) { dKs[idx] = 0.f; dVs[idx] = 0.f; }
+  const T* qg = reinterpret_cast<const T*>(p.q);
+  const T* dog = reinterpret_cast<const T*>(p.dctx);
+  const T* og = reinterpret_cast<const T*>(p.ctx);
+  T* dqg = reinterpret_cast<T*>(p.dq);
+
+  for (int q0 = 0; q0 < Lq; q0 += TQ) {
+    __syncthreads();  // previous tile fully consumed (and the initial staging visible)
+    for (int idx = tid; idx < TQ * dk; idx += 256) {
+      const int i = idx / dk, c = idx % dk, qi = q0 + i;
+      float qv = 0.f, dov = 0.f;
+      if (qi < Lq) {
+        qv = to_f32(qg[((long)b * Lq + qi) * p.ldq + (long)h * dk + c]);
+        dov = to_f32(dog[((long)b * Lq + qi) * p.lddo + (long)h * dk + c]);
+      }
+      Qs[idx] = qv; dOs[idx] = dov;
+    }
+    for (int i = wave; i < TQ; i += 4) {
+      const int qi = q0 + i;
+      float acc = 0.f;
+      if (qi < Lq) {
+        for (int c = lane; c < dk; c += 64)
+          acc += to_f32(dog[((long)b * Lq + qi) * p.lddo + (long)h * dk + c]) * to_f32(og[((long)b * Lq + qi) * p.ldo + (long)h * dk + c]);
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) {
+        delta[i] = acc;
+        lses[i] = qi < Lq ? p.lse[((long)b * p.H + h) * Lq + qi] : 0.f;
+      }
+    }
+    __syncthreads();
+
+    for (int idx = tid; idx < TQ * Lk; idx += 256) {
+      const int i = idx / Lk, j = idx % Lk, qi = q0 + i;
+      float pd = 0.f, ds = 0.f;
+      if (qi < Lq && !(p.causal && j > qi)) {
+        float s = 0.f, dpd = 0.f;
+        const T* kr = Ks + j * kst;
+        const T* vr = Vs + j * kst;
+        const float* qr = Qs + i * dk;
+        const float* dor = dOs + i * dk;
+        for (int c = 0; c < dk; c += VEC) {
+          float kv[VEC], vv[VEC];
+          load_vec_f32<T>(kr + c, kv);
+          load_vec_f32<T>(vr + c, vv);
+#pragma unroll
+          for (int u = 0; u < VEC; ++u) { s += qr[c + u] * kv[u]; dpd += dor[c + u] * vv[u]; }
+        }
+        if (p.bias) s += p.bias[((long)h * Lq + qi) * Lk + j];
+        const float pr = __expf(s - lses[i]);
+        const float mlt = drop_mult(dc, (((uint64_t)b * p.H + h) * Lq + qi) * (uint64_t)Lk + j);
+        pd = pr * mlt;
+        ds = pr * (dpd * mlt - delta[i]);
+        if (p.dbias) atomicAdd(p.dbias + ((long)h * Lq + qi) * Lk + j, ds);
+      }
+      Ps[i * pst + j] = pd;
+      dSs[i * pst + j] = ds;
+    }
+    __syncthreads();
+
+    for (int idx = tid; idx < Lk * dk; idx += 256) {
+      const int j = idx / dk, c = idx % dk;
+      float av = 0.f, ak = 0.f;
+#pragma unroll 4
+      for (int i = 0; i < TQ; ++i) {
+        av += Ps[i * pst + j] * dOs[i * dk + c];
+        ak += dSs[i * pst + j] * Qs[i * dk + c];
+      }
+      dVs[idx] += av;
+      dKs[idx] += ak;
+    }
+    for (int idx = tid; idx < TQ * dk; idx += 256) {
+      const int i = idx / dk, c = idx % dk, qi = q0 + i;
+      if (qi >= Lq) continue;
+      float a = 0.f;
+      const float* dsr = dSs + i * pst;
+      for (int j = 0; j < Lk; ++j) a += dsr[j] * to_f32(Ks[j * kst + c]);
+      dqg[((long)b * Lq + qi) * p.lddq + (long)h * dk + c] = from_f32<T>(a);
+    }
+  }
+  __syncthreads();
+  T* dkg = reinterpret_cast<T*>(p.dkk);
+  T* dvg = reinterpret_cast<T*>(p.dv);
+  for (int idx = tid; idx < Lk * dk; idx += 256) {
+    const int j = idx / dk, c = idx % dk;
+    dkg[((long)b * Lk + j) * p.lddk + (long)h * dk + c] = from_f32<T>(dKs[idx]);
+    dvg[((long)b * Lk + j) * p.lddv + (long)h * dk + c] = from_f32<T>(dVs[idx]);
+  }
+}
+
+template <typename K>
+static int set_lds(K kern, size_t bytes) {
+  if (bytes > 160 * 1024) return KLAB_ERR_UNSUPPORTED;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return e == hipSuccess ? KLAB_OK : (int)e;
+}
+
+}  // namespace klab
+
+using namespace klab;
+
+static int check_attn(const klab_attn_args* a) {
+  if (!a || !a->q || !a->k || !a->v || !a->ctx) return KLAB_ERR_BADARG;
+  const int vec = a->dtype == KLAB_BF16 ? 8 : 4;
+  if (a->dk % vec || a->ldq % vec || a->ldk % vec || a->ldv % vec) return KLAB_ERR_UNSUPPORTED;
+  if (a->dtype != KLAB_F32 && a->dtype != KLAB_BF16) return KLAB_ERR_BADARG;
+  return KLAB_OK;
+}
+
+static AttnP to_p(const klab_attn_args* a) {
+  AttnP p;
+  p.q = a->q; p.ldq = a->ldq; p.k = a->k; p.ldk = a->ldk; p.v = a->v; p.ldv = a->ldv;
+  p.bias = a->bias; p.causal = a->causal; p.ctx = a->ctx; p.ldo = a->ldo; p.lse = a->lse;
+  p.B = a->B; p.H = a->H; p.Lq = a->Lq; p.Lk = a->Lk; p.dk = a->dk;
+  p.p = a->drop_p; p.seed = a->seed_dev; p.tag = a->drop_tag;
+  p.dctx = a->dctx; p.lddo = a->lddo; p.dq = a->dq; p.lddq = a->lddq; p.dkk = a->dk_out; p.lddk = a->lddk;
+  p.dv = a->dv; p.lddv = a->lddv; p.dbias = a->dbias;
+  return p;
+}
+
+extern "C" int klab_t5_attn_fwd(const klab_attn_args* a, void* stream) {
+  int rc = check_attn(a);
+  if (rc) return rc;
+  if (a->B <= 0 || a->Lq <= 0 || a->Lk <= 0) return KLAB_OK;
+  const size_t es = a->dtype == KLAB_BF16 ? 2 : 4;
+  const int vec = a->dtype == KLAB_BF16 ? 8 : 4;
+  const size_t lds = 2 * (size_t)a->Lk * (a->dk + vec) * es + (size_t)TQ * a->dk * 4 + (size_t)TQ * (a->Lk + 1) * 4;
+  AttnP p = to_p(a);
+  dim3 grid((a->Lq + TQ - 1) / TQ, a->B * a->H);
+  hipStream_t s = (hipStream_t)stream;
+  if (a->dtype == KLAB_BF16) {
+    rc = set_lds(t5_attn_fwd_kernel<bf16_t>, lds); if (rc) return rc;
+    hipLaunchKernelGGL(t5_attn_fwd_kernel<bf16_t>, grid, dim3(256), lds, s, p);
+  } else {
+    rc = set_lds(t5_attn_fwd_kernel<float>, lds); if (rc) return rc;
+    hipLaunchKernelGGL(t5_attn_fwd_kernel<float>, grid, dim3(256), lds, s, p);
+  }
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+
+extern "C" int klab_t5_attn_bwd(const klab_attn_args* a, void* stream) {
+  int rc = check_attn(a);
+  if (rc) return rc;
+  if (!a->dctx || !a->dq || !a->dk_out || !a->dv || !a->lse) return KLAB_ERR_BADARG;
+  if (a->B <= 0 || a->Lq <= 0 || a->Lk <= 0) return KLAB_OK;
+  const size_t es = a->dtype == KLAB_BF16 ? 2 : 4;
+  const int vec = a->dtype == KLAB_BF16 ? 8 : 4;
+  const size_t lds = 2 * (size_t)a->Lk * (a->dk + vec) * es + 2 * (size_t)a->Lk * a->dk * 4 + 2 * (size_t)TQ * a->dk * 4 +
+                     2 * (size_t)TQ * (a->Lk + 1) * 4 + 2 * TQ * 4;
+  AttnP p = to_p(a);
+  dim3 grid(a->B * a->H);
+  hipStream_t s = (hipStream_t)stream;
+  if (a->dtype == KLAB_BF16) {
+    rc = set_lds(t5_attn_bwd_kernel<bf16_t>, lds); if (rc) return rc;
+    hipLaunchKernelGGL(t5_attn_bwd_kernel<bf16_t>, grid, dim3(256), lds, s, p);
+  } else {
+    rc = set_lds(t5_attn_bwd_kernel<float>, lds); if (rc) return rc;
+    hipLaunchKernelGGL(t5_attn_bwd_kernel<float>, grid, dim3(256), lds, s, p);
+  }
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}

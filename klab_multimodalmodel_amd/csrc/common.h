@@ -1,0 +1,106 @@
+// Shared device helpers for the gfx950 (CDNA4) kernels of the Swin-V2 -> T5 caption-training path.
+// wave = 64 lanes everywhere; no CUDA compatibility paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define KLAB_OK 0
+#define KLAB_ERR_UNSUPPORTED (-2)
+#define KLAB_ERR_BADARG (-3)
+
+#define KLAB_F32 0
+#define KLAB_BF16 1
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define KLAB_LAUNCH_CHECK()                          \
+  do {                                               \
+    hipError_t e__ = hipGetLastError();              \
+    if (e__ != hipSuccess) return (int)e__;          \
+  } while (0)
+
+namespace klab {
+
+template <typename T> struct TypeTag;
+template <> struct TypeTag<float> { static constexpr int id = KLAB_F32; };
+template <> struct TypeTag<bf16_t> { static constexpr int id = KLAB_BF16; };
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }  // v_cvt_pk_bf16_f32 (RNE, NaN-safe)
+
+// ---- counter-based dropout RNG -------------------------------------------------------------
+// keep(idx) is a pure function of (seed word in device memory, per-site tag, element index), so the
+// backward pass regenerates the forward mask instead of storing it (reference: nn.Dropout,
+// HF/t5:80,135,168,382,411,651 -- matched statistically, not bitwise).
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+struct DropCtx {
+  uint32_t key;     // mix(seed, tag)
+  uint32_t thresh;  // drop if hash < thresh
+  float scale;      // 1/(1-p)
+  bool on;
+};
+__device__ __forceinline__ DropCtx make_drop(const uint32_t* seed_dev, uint32_t tag, float p) {
+  DropCtx d;
+  d.on = (p > 0.f) && (seed_dev != nullptr);
+  d.key = 0; d.thresh = 0; d.scale = 1.f;
+  if (d.on) {
+    d.key = mix32(seed_dev[0] * 0x9E3779B1u + tag * 0x7FEB352Du + 0x165667B1u);
+    double t = (double)p * 4294967296.0;
+    d.thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+    d.scale = 1.f / (1.f - p);
+  }
+  return d;
+}
+// multiplier applied to the element: 0 (dropped) or 1/(1-p)
+__device__ __forceinline__ float drop_mult(const DropCtx& d, uint64_t idx) {
+  if (!d.on) return 1.f;
+  uint32_t h = mix32((uint32_t)idx * 0x9E3779B1u + d.key);
+  h = mix32(h ^ ((uint32_t)(idx >> 32) * 0x85EBCA77u + 0x27D4EB2Fu));
+  return h < d.thresh ? 0.f : d.scale;
+}
+
+// ---- wave / block reductions ---------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// sub-wave group reductions (G = power of two lanes, aligned)
+template <int G> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int G> __device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+  float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// vector load/store of VEC = 16/sizeof(T) elements
+template <typename T> struct Vec16;
+template <> struct Vec16<float> { typedef f32x4 type; static constexpr int N = 4; };
+template <> struct Vec16<bf16_t> { typedef bf16x8 type; static constexpr int N = 8; };
+
+}  // namespace klab

@@ -1,0 +1,395 @@
+// HBM-bound glue kernels of the path: weight cast/pack, embedding gather / scatter-add, relative
+// position bias gather / scatter, LM-head cross-entropy (+ d logits in place), patch im2col,
+// patch-merge gather / scatter, bias-gradient column sums.  All are coalesced 16-byte streams with
+// wave-shuffle reductions; none is reshaped into a GEMM.
+#include <math.h>
+
+#include "common.h"
+#include "klab_mm.h"
+
+namespace klab {
+
+// ---- multi-tensor f32 -> T cast / pack ------------------------------------------------------
+// The master weights stay fp32 nn.Parameters (the reference trains in fp32, ref/train.py:25-28);
+// once per step the GEMM weights are cast into ONE arena in compute dtype, laid out so that q|k|v
+// (and all decoder layers' cross k|v) are row-concatenated: fused projections need no copies.
+struct CastDesc { const float* src; long dst_off; long n4_prefix; };  // prefix in units of 4 elements
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_pack_kernel(const CastDesc* __restrict__ d, int nd, long total4, T* __restrict__ dst) {
+  for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total4; g += (long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = nd - 1;
+    while (lo < hi) {  // last descriptor with prefix <= g
+      const int mid = (lo + hi + 1) >> 1;
+      if (d[mid].n4_prefix <= g) lo = mid; else hi = mid - 1;
+    }
+    const long local = (g - d[lo].n4_prefix) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(d[lo].src + local);
+    T* o = dst + d[lo].dst_off + local;
+    if constexpr (sizeof(T) == 2) *reinterpret_cast<bf16x4*>(o) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    else *reinterpret_cast<f32x4*>(o) = v;
+  }
+}
+
+// ---- embedding gather (+ T5 _shift_right, HF/t5:618-637) + input dropout (HF/t5:725) -----------
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restrict__ ids, int shift_right, int L, int start_id, int pad_id,
+                                                        const float* __restrict__ table, int vocab, float* __restrict__ out, int rows, int d,
+                                                        float p, const uint32_t* seed, uint32_t tag, int* __restrict__ err) {
+  const int lane = threadIdx.x & 63;
+  const DropCtx dc = make_drop(seed, tag, p);
+  for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
+    long long id;
+    if (shift_right) {
+      const int t = row % L;
+      id = t == 0 ? start_id : ids[row - 1];
+      if (id == -100) id = pad_id;
+    } else {
+      id = ids[row];
+    }
+    if (id < 0 || id >= vocab) { if (lane == 0 && err) atomicOr(err, 1); id = 0; }
+    const float* src = table + id * d;
+    for (int c = lane * 4; c < d; c += 256) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] *= drop_mult(dc, (uint64_t)row * d + c + i);
+      *reinterpret_cast<f32x4*>(out + row * d + c) = v;
+    }
+  }
+}
+
+// scatter-add of d(hidden_0) into the tied embedding gradient (second contributor of shared.weight,
+// SURVEY §2.4 "tied-weight note"); one wave per row => each atomic wave-instruction is 256
+// contiguous bytes (MI355X atomic-rate shape).
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restrict__ ids, int shift_right, int L, int start_id, int pad_id,
+                                                        const float* __restrict__ dh, float* __restrict__ dtable, int vocab, int rows, int d,
+                                                        float p, const uint32_t* seed, uint32_t tag) {
+  const int lane = threadIdx.x & 63;
+  const DropCtx dc = make_drop(seed, tag, p);
+  for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
+    long long id;
+    if (shift_right) {
+      const int t = row % L;
+      id = t == 0 ? start_id : ids[row - 1];
+      if (id == -100) id = pad_id;
+    } else {
+      id = ids[row];
+    }
+    if (id < 0 || id >= vocab) continue;
+    float* dst = dtable + id * d;
+    for (int c = lane; c < d; c += 64) atomicAdd(dst + c, dh[row * d + c] * drop_mult(dc, (uint64_t)row * d + c));
+  }
+}
+
+// ---- T5 relative position bias (HF/t5:264-279): bias[h,i,j] = table[bucket[i,j], h] -----------
+// bucket[Lq,Lk] is computed on the host with the reference's exact float-log arithmetic (HF/t5:216-262).
+__global__ void relbias_fwd_kernel(const float* __restrict__ table, const int* __restrict__ bucket, float* __restrict__ bias, int H, int LL) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)H * LL) return;
+  const int h = idx / LL, ij = idx % LL;
+  bias[idx] = table[bucket[ij] * H + h];
+}
+__global__ void relbias_bwd_kernel(const float* __restrict__ dbias, const int* __restrict__ bucket, float* __restrict__ dtable, int H, int LL, int nb) {
+  // one block per head: LDS histogram over the <=64 buckets, then one atomic per bucket
+  __shared__ float acc[64];
+  const int h = blockIdx.x;
+  for (int i = threadIdx.x; i < 64; i += blockDim.x) acc[i] = 0.f;
+  __syncthreads();
+  for (int ij = threadIdx.x; ij < LL; ij += blockDim.x) atomicAdd(&acc[bucket[ij]], dbias[(long)h * LL + ij]);
+  __syncthreads();
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) atomicAdd(dtable + i * H + h, acc[i]);
+}
+
+// ---- LM-head cross-entropy (HF/t5:1050-1054: CrossEntropyLoss(ignore_index=-100), mean over the
+//      non-ignored rows; pads (id 0) ARE scored) -------------------------------------
+__global__ void ce_count_kernel(const long long* __restrict__ labels, int rows, float* __restrict__ inv_n) {
+  __shared__ int red[4];
+  int c = 0;
+  for (int i = threadIdx.x; i < rows; i += blockDim.x) c += labels[i] != -100;
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int n = red[0] + red[1] + red[2] + red[3];
+    inv_n[0] = n > 0 ? 1.f / (float)n : 0.f;   // (reference would produce NaN for n == 0)
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ce_fwd_kernel(T* __restrict__ logits, long ld, const long long* __restrict__ labels, int V,
+                                                     const float* __restrict__ inv_n, float* __restrict__ loss_row, int write_grad) {
+  constexpr int VEC = Vec16<T>::N;
+  using VT = typename Vec16<T>::type;
+  __shared__ float red[8];
+  const long row = blockIdx.x;
+  const int tid = threadIdx.x;
+  T* x = logits + row * ld;
+  const long long lab = labels[row];
+  float m = -INFINITY, s = 0.f;
+  for (int c = tid * VEC; c < V; c += 256 * VEC) {
+    VT v = *reinterpret_cast<const VT*>(x + c);
+    float mx = to_f32(v[0]);
+#pragma unroll
+    for (int u = 1; u < VEC; ++u) mx = fmaxf(mx, to_f32(v[u]));
+    const float mn = fmaxf(m, mx);
+    float a = 0.f;
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) a += __expf(to_f32(v[u]) - mn);
+    s = s * __expf(m - mn) + a;
+    m = mn;
+  }
+  // block-wide (max, sum) merge
+  float wm = wave_max(m);
+  float ws = wave_sum(m == -INFINITY ? 0.f : s * __expf(m - wm));  // lanes/waves with no column contribute 0, not NaN
+  if ((tid & 63) == 0) { red[tid >> 6] = wm; red[4 + (tid >> 6)] = ws; }
+  __syncthreads();
+  const float bm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float bs = 0.f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) bs += red[w] == -INFINITY ? 0.f : red[4 + w] * __expf(red[w] - bm);
+  const float lse = bm + __logf(bs);
+  const bool valid = lab != -100;
+  if (tid == 0) loss_row[row] = valid ? (lse - to_f32(x[lab])) : 0.f;
+  if (!write_grad) return;
+  __syncthreads();  // x[lab] read above before it is overwritten below
+  const float g = valid ? inv_n[0] : 0.f;
+  for (int c = tid * VEC; c < V; c += 256 * VEC) {
+    VT v = *reinterpret_cast<const VT*>(x + c);
+    VT o;
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) {
+      float pr = __expf(to_f32(v[u]) - lse);
+      if (c + u == lab) pr -= 1.f;
+      o[u] = from_f32<T>(pr * g);
+    }
+    *reinterpret_cast<VT*>(x + c) = o;
+  }
+}
+
+__global__ void ce_reduce_kernel(const float* __restrict__ loss_row, int rows, const float* __restrict__ inv_n, float* __restrict__ loss) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < rows; i += blockDim.x) a += loss_row[i];  // fixed order => bit-reproducible
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = (red[0] + red[1] + red[2] + red[3]) * inv_n[0];
+}
+
+// ---- Swin patch embedding im2col (Conv2d k4 s4 == GEMM over 48-wide patches, HF/swinv2:281) ----
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ pix, T* __restrict__ out, int B, int Cin, int Himg, int P) {
+  const int R = Himg / P;
+  const int K = Cin * P * P;
+  const long total = (long)B * R * R * K;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int k = idx % K;
+    const long t = idx / K;
+    const int px = k % P, py = (k / P) % P, c = k / (P * P);
+    const int x = t % R, y = (t / R) % R;
+    const long b = t / ((long)R * R);
+    out[idx] = from_f32<T>(pix[((b * Cin + c) * Himg + (y * P + py)) * Himg + (x * P + px)]);
+  }
+}
+
+// ---- Swin patch merging gather (HF/swinv2:342-351): [B,R,R,C] -> [B,(R/2)^2, 4C] in the order
+//      (0,0),(1,0),(0,1),(1,1) (row offset, col offset) ------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void merge_gather_kernel(const float* __restrict__ x, T* __restrict__ out, int B, int R, int C) {
+  const int R2 = R / 2;
+  const long total4 = (long)B * R2 * R2 * C;  // in units of 4 elements: 4C per token / 4
+  for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total4; g += (long)gridDim.x * blockDim.x) {
+    const int c4 = g % C;            // 4-element group within the 4C row
+    const long t = g / C;
+    const int q = (c4 * 4) / C, c = (c4 * 4) % C;
+    const int dy = q & 1, dx = q >> 1;
+    const int x2 = t % R2, y2 = (t / R2) % R2;
+    const long b = t / ((long)R2 * R2);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((b * R + (2 * y2 + dy)) * R + (2 * x2 + dx)) * C + c);
+    T* o = out + t * 4L * C + c4 * 4;
+    if constexpr (sizeof(T) == 2) *reinterpret_cast<bf16x4*>(o) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    else *reinterpret_cast<f32x4*>(o) = v;
+  }
+}
+// scatter of d(merged rows) [B,(R/2)^2,4C] f32 back to dx [B,R,R,C] f32 (a permutation: plain stores)
+__global__ __launch_bounds__(256) void merge_scatter_kernel(const float* __restrict__ dm, float* __restrict__ dx, int B, int R, int C) {
+  const int R2 = R / 2;
+  const long total4 = (long)B * R2 * R2 * C;
+  for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total4; g += (long)gridDim.x * blockDim.x) {
+    const int c4 = g % C;
+    const long t = g / C;
+    const int q = (c4 * 4) / C, c = (c4 * 4) % C;
+    const int dy = q & 1, dxo = q >> 1;
+    const int x2 = t % R2, y2 = (t / R2) % R2;
+    const long b = t / ((long)R2 * R2);
+    *reinterpret_cast<f32x4*>(dx + ((b * R + (2 * y2 + dy)) * R + (2 * x2 + dxo)) * C + c) =
+        *reinterpret_cast<const f32x4*>(dm + t * 4L * C + c4 * 4);
+  }
+}
+
+// ---- column sums: dbias[n] += sum_m dY[m,n]  (bias gradients of the Swin Linears) --------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, long ld, int M, int N, float* __restrict__ out) {
+  // block = 64 columns x 4 row-lanes; grid.x over column tiles, grid.y over row slabs
+  __shared__ float red[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  float a = 0.f;
+  if (col < N)
+    for (long m = (long)blockIdx.y * 4 + rl; m < M; m += (long)gridDim.y * 4) a += to_f32(dy[m * ld + col]);
+  red[rl][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (rl == 0 && col < N) atomicAdd(out + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// ---- f32 -> T convert (optionally scaled) and f32 axpy ---------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void convert_kernel(const float* __restrict__ x, T* __restrict__ y, long n4, float scale) {
+  for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < n4; g += (long)gridDim.x * blockDim.x) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + g * 4);
+    if constexpr (sizeof(T) == 2) *reinterpret_cast<bf16x4*>(y + g * 4) = bf16x4{(bf16_t)(v[0] * scale), (bf16_t)(v[1] * scale), (bf16_t)(v[2] * scale), (bf16_t)(v[3] * scale)};
+    else *reinterpret_cast<f32x4*>(y + g * 4) = f32x4{v[0] * scale, v[1] * scale, v[2] * scale, v[3] * scale};
+  }
+}
+__global__ __launch_bounds__(256) void add_f32_kernel(float* __restrict__ y, const float* __restrict__ x, long n4) {
+  for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < n4; g += (long)gridDim.x * blockDim.x) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(y + g * 4);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(x + g * 4);
+    a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+    *reinterpret_cast<f32x4*>(y + g * 4) = a;
+  }
+}
+
+static inline unsigned stream_grid(long work_items) {
+  long g = (work_items + 255) / 256;
+  if (g < 1) g = 1;
+  if (g > 2048) g = 2048;  // cap + grid-stride (memory-bound grid sizing rule)
+  return (unsigned)g;
+}
+
+}  // namespace klab
+
+using namespace klab;
+
+extern "C" int klab_cast_pack(const void* desc_dev, int ndesc, long total4, void* dst, int dtype, void* stream) {
+  if (!desc_dev || !dst || ndesc <= 0) return KLAB_ERR_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == KLAB_BF16)
+    hipLaunchKernelGGL(cast_pack_kernel<bf16_t>, dim3(stream_grid(total4)), dim3(256), 0, s, (const CastDesc*)desc_dev, ndesc, total4, (bf16_t*)dst);
+  else
+    hipLaunchKernelGGL(cast_pack_kernel<float>, dim3(stream_grid(total4)), dim3(256), 0, s, (const CastDesc*)desc_dev, ndesc, total4, (float*)dst);
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+
+extern "C" int klab_embed_fwd(const long long* ids, int shift_right, int L, int start_id, int pad_id, const float* table, int vocab,
+                              float* out, int rows, int d, float drop_p, const uint32_t* seed_dev, uint32_t tag, int* err_flag,
+                              void* stream) {
+  if (!ids || !table || !out || (d & 3)) return KLAB_ERR_BADARG;
+  if (rows <= 0) return KLAB_OK;
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(stream_grid((long)rows * 64)), dim3(256), 0, (hipStream_t)stream, ids, shift_right, L, start_id,
+                     pad_id, table, vocab, out, rows, d, drop_p, seed_dev, tag, err_flag);
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+
+extern "C" int klab_embed_bwd(const long long* ids, int shift_right, int L, int start_id, int pad_id, const float* dh, float* dtable,
+                              int vocab, int rows, int d, float drop_p, const uint32_t* seed_dev, uint32_t tag, void* stream) {
+  if (!ids || !dh || !dtable) return KLAB_ERR_BADARG;
+  if (rows <= 0) return KLAB_OK;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(stream_grid((long)rows * 64)), dim3(256), 0, (hipStream_t)stream, ids, shift_right, L, start_id,
+                     pad_id, dh, dtable, vocab, rows, d, drop_p, seed_dev, tag);
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+
+extern "C" int klab_relbias_fwd(const float* table, const int* bucket, float* bias, int heads, int Lq, int Lk, void* stream) {
+  if (!table || !bucket || !bias) return KLAB_ERR_BADARG;
+  const long tot = (long)heads * Lq * Lk;
+  hipLaunchKernelGGL(relbias_fwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table, bucket, bias, heads, Lq * Lk);
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+
+extern "C" int klab_relbias_bwd(const float* dbias, const int* bucket, float* dtable, int heads, int Lq, int Lk, int nbuckets, void* stream) {
+  if (!dbias || !bucket || !dtable) return KLAB_ERR_BADARG;
+  if (nbuckets > 64) return KLAB_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(relbias_bwd_kernel, dim3(heads), dim3(256), 0, (hipStream_t)stream, dbias, bucket, dtable, heads, Lq * Lk, nbuckets);
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+
+extern "C" int klab_ce_fwd(void* logits, long ld, int dtype, const long long* labels, int rows, int V, float* inv_n, float* loss_row,
+                           float* loss, int write_grad, void* stream) {
+  if (!logits || !labels || !inv_n || !loss_row || !loss) return KLAB_ERR_BADARG;
+  const int vec = dtype == KLAB_BF16 ? 8 : 4;
+  if (V % vec || ld % vec) return KLAB_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(256), 0, s, labels, rows, inv_n);
+  KLAB_LAUNCH_CHECK();
+  if (dtype == KLAB_BF16)
+    hipLaunchKernelGGL(ce_fwd_kernel<bf16_t>, dim3(rows), dim3(256), 0, s, (bf16_t*)logits, ld, labels, V, inv_n, loss_row, write_grad);
+  else
+    hipLaunchKernelGGL(ce_fwd_kernel<float>, dim3(rows), dim3(256), 0, s, (float*)logits, ld, labels, V, inv_n, loss_row, write_grad);
+  KLAB_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, s, loss_row, rows, inv_n, loss);
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+
+extern "C" int klab_im2col_patch(const float* pixels, void* out, int dtype, int B, int Cin, int Himg, int P, void* stream) {
+  if (!pixels || !out || Himg % P) return KLAB_ERR_BADARG;
+  const long total = (long)B * (Himg / P) * (Himg / P) * Cin * P * P;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == KLAB_BF16) hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(stream_grid(total)), dim3(256), 0, s, pixels, (bf16_t*)out, B, Cin, Himg, P);
+  else hipLaunchKernelGGL(im2col_kernel<float>, dim3(stream_grid(total)), dim3(256), 0, s, pixels, (float*)out, B, Cin, Himg, P);
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+
+extern "C" int klab_merge_gather(const float* x, void* out, int dtype, int B, int R, int C, void* stream) {
+  if (!x || !out || (R & 1) || (C & 3)) return KLAB_ERR_BADARG;
+  const long total4 = (long)B * (R / 2) * (R / 2) * C;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == KLAB_BF16) hipLaunchKernelGGL(merge_gather_kernel<bf16_t>, dim3(stream_grid(total4)), dim3(256), 0, s, x, (bf16_t*)out, B, R, C);
+  else hipLaunchKernelGGL(merge_gather_kernel<float>, dim3(stream_grid(total4)), dim3(256), 0, s, x, (float*)out, B, R, C);
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+
+extern "C" int klab_merge_scatter(const float* dmerged, float* dx, int B, int R, int C, void* stream) {
+  if (!dmerged || !dx || (R & 1) || (C & 3)) return KLAB_ERR_BADARG;
+  const long total4 = (long)B * (R / 2) * (R / 2) * C;
+  hipLaunchKernelGGL(merge_scatter_kernel, dim3(stream_grid(total4)), dim3(256), 0, (hipStream_t)stream, dmerged, dx, B, R, C);
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+
+extern "C" int klab_colsum(const void* dy, long ld, int dtype, int M, int N, float* out, void* stream) {
+  if (!dy || !out) return KLAB_ERR_BADARG;
+  int gy = (M + 255) / 256;
+  gy = gy < 1 ? 1 : (gy > 256 ? 256 : gy);
+  dim3 grid((N + 63) / 64, gy);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == KLAB_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, ld, M, N, out);
+  else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, ld, M, N, out);
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+
+extern "C" int klab_convert(const float* x, void* y, int dtype, long n, float scale, void* stream) {
+  if (!x || !y || (n & 3)) return KLAB_ERR_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == KLAB_BF16) hipLaunchKernelGGL(convert_kernel<bf16_t>, dim3(stream_grid(n / 4)), dim3(256), 0, s, x, (bf16_t*)y, n / 4, scale);
+  else hipLaunchKernelGGL(convert_kernel<float>, dim3(stream_grid(n / 4)), dim3(256), 0, s, x, (float*)y, n / 4, scale);
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+
+extern "C" int klab_add_f32(float* y, const float* x, long n, void* stream) {
+  if (!x || !y || (n & 3)) return KLAB_ERR_BADARG;
+  hipLaunchKernelGGL(add_f32_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, y, x, n / 4);
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+
+extern "C" int klab_version(void) { return 1; }

@@ -1,0 +1,342 @@
+// Row-normalisation kernels (HBM-bound): T5 RMS-norm (HF/t5:59-72) and Swin-V2 res-post-norm
+// LayerNorm (HF/swinv2:697-702, 242, 354, 953), forward and backward.
+// One wave (64 lanes) per row, 16-B vector accesses, fp32 statistics, wave-shuffle reductions.
+// Outputs can be written through a row remap (row -> (row / grp) * grp_stride + row % grp + off)
+// so that the Swin final LayerNorm and the language-encoder final RMS-norm write straight into the
+// [B, N_img + Ls, d] encoder-input buffer: the torch.cat of ref/models/model.py:23 costs nothing.
+#include "common.h"
+#include "klab_mm.h"
+
+namespace klab {
+
+__device__ __forceinline__ long remap_row(long row, int grp, int grp_stride, int off) {
+  if (grp <= 0) return row;
+  return (row / grp) * (long)grp_stride + (row % grp) + off;
+}
+
+template <typename T>
+__device__ __forceinline__ void store4(T* p, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void store4<float>(float* p, float a, float b, float c, float d) {
+  *reinterpret_cast<f32x4*>(p) = f32x4{a, b, c, d};
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+  *reinterpret_cast<bf16x4*>(p) = bf16x4{(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
+}
+template <typename T> __device__ __forceinline__ f32x4 load4(const T* p);
+template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> __device__ __forceinline__ f32x4 load4<bf16_t>(const bf16_t* p) {
+  bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+  return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+
+// ------------------------------------------------------------------------------------------
+// RMS-norm forward: y = drop(x * rsqrt(mean(x^2)+eps) * w)
+// ------------------------------------------------------------------------------------------
+template <typename TY>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          TY* __restrict__ y, float* __restrict__ y32, float* __restrict__ rstd, int rows,
+                                                          int d, float eps, int grp, int grp_stride, int off, float p,
+                                                          const uint32_t* seed, uint32_t tag) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const DropCtx dc = make_drop(seed, tag, p);
+  for (long row = (long)blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * wpb) {
+    const float* xr = x + row * d;
+    float ss = 0.f;
+    for (int c = lane * 4; c < d; c += 256) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+      ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    ss = wave_sum(ss);
+    const float r = rsqrtf(ss / (float)d + eps);
+    if (lane == 0 && rstd) rstd[row] = r;
+    const long orow = remap_row(row, grp, grp_stride, off);
+    for (int c = lane * 4; c < d; c += 256) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+      f32x4 g = *reinterpret_cast<const f32x4*>(w + c);
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = g[i] * (v[i] * r) * drop_mult(dc, (uint64_t)orow * d + c + i);
+      if (y) store4<TY>(y + orow * d + c, o[0], o[1], o[2], o[3]);
+      if (y32) store4<float>(y32 + orow * d + c, o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// RMS-norm backward.
+//   dy_eff = dy * dropmult_y            (dropout that followed the norm, if any)
+//   dx     = dres + r*w*dy_eff - x * r^3/d * sum(dy_eff*w*x)
+//   dw    += sum_rows dy_eff * x * r    (per-wave register partials, then one f32 atomic per column)
+//   dxt    = T(dx * dropmult_prev)      (grad of the previous sub-layer's GEMM output, ready as a
+//                                        bf16 GEMM operand: the residual add + dropout of HF/t5:400,141)
+// ------------------------------------------------------------------------------------------
+template <typename TY, int MAXC>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          const float* __restrict__ w, const float* __restrict__ rstd,
+                                                          const float* __restrict__ dres, float* __restrict__ dx,
+                                                          TY* __restrict__ dxt, float* __restrict__ dw, int rows, int d,
+                                                          int grp, int grp_stride, int off, float p_y, uint32_t tag_y,
+                                                          float p_prev, uint32_t tag_prev, const uint32_t* seed) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const DropCtx dcy = make_drop(seed, tag_y, p_y);
+  const DropCtx dcp = make_drop(seed, tag_prev, p_prev);
+  float dwacc[MAXC][4];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) dwacc[i][0] = dwacc[i][1] = dwacc[i][2] = dwacc[i][3] = 0.f;
+  for (long row = (long)blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * wpb) {
+    const float* xr = x + row * d;
+    const long yrow = remap_row(row, grp, grp_stride, off);  // dy lives in the remapped space
+    const float* dyr = dy + yrow * d;
+    const float r = rstd[row];
+    float dot = 0.f;
+    for (int c = lane * 4; c < d; c += 256) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+      f32x4 g = *reinterpret_cast<const f32x4*>(w + c);
+      f32x4 e = *reinterpret_cast<const f32x4*>(dyr + c);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dot += e[i] * drop_mult(dcy, (uint64_t)yrow * d + c + i) * g[i] * v[i];
+    }
+    dot = wave_sum(dot);
+    const float k = dot * r * r * r / (float)d;
+#pragma unroll
+    for (int ci = 0; ci < MAXC; ++ci) {  // compile-time ci keeps dwacc in registers
+      const int c = lane * 4 + ci * 256;
+      if (c >= d) continue;
+      f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+      f32x4 g = *reinterpret_cast<const f32x4*>(w + c);
+      f32x4 e = *reinterpret_cast<const f32x4*>(dyr + c);
+      float o[4], ot[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float de = e[i] * drop_mult(dcy, (uint64_t)yrow * d + c + i);
+        o[i] = r * g[i] * de - v[i] * k;
+        dwacc[ci][i] += de * v[i] * r;
+      }
+      if (dres) {
+        f32x4 q = *reinterpret_cast<const f32x4*>(dres + row * d + c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] += q[i];
+      }
+      if (dx) store4<float>(dx + row * d + c, o[0], o[1], o[2], o[3]);
+      if (dxt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ot[i] = o[i] * drop_mult(dcp, (uint64_t)row * d + c + i);
+        store4<TY>(dxt + row * d + c, ot[0], ot[1], ot[2], ot[3]);
+      }
+    }
+  }
+  if (dw) {
+#pragma unroll
+    for (int ci = 0; ci < MAXC; ++ci) {
+      const int c = lane * 4 + ci * 256;
+      if (c >= d) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) atomicAdd(dw + c + i, dwacc[ci][i]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm forward (Swin-V2): out = shortcut + (LN(y) * gamma + beta); optional T copy.
+// ------------------------------------------------------------------------------------------
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const TI* __restrict__ y, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const float* __restrict__ shortcut,
+                                                            float* __restrict__ out, TO* __restrict__ outt, float* __restrict__ mean,
+                                                            float* __restrict__ rstd, int rows, int C, float eps, int grp,
+                                                            int grp_stride, int off, float p, const uint32_t* seed, uint32_t tag) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const DropCtx dc = make_drop(seed, tag, p);
+  for (long row = (long)blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * wpb) {
+    const TI* yr = y + row * C;
+    float s = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+      f32x4 v = load4<TI>(yr + c);
+      s += v[0] + v[1] + v[2] + v[3];
+    }
+    const float mu = wave_sum(s) / (float)C;
+    float ss = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+      f32x4 v = load4<TI>(yr + c);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { float t = v[i] - mu; ss += t * t; }
+    }
+    const float r = rsqrtf(wave_sum(ss) / (float)C + eps);
+    if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = r; }
+    const long orow = remap_row(row, grp, grp_stride, off);
+    for (int c = lane * 4; c < C; c += 256) {
+      f32x4 v = load4<TI>(yr + c);
+      f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+      f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = (v[i] - mu) * r * g[i] + b[i];
+      if (shortcut) {
+        f32x4 q = *reinterpret_cast<const f32x4*>(shortcut + row * C + c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] += q[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] *= drop_mult(dc, (uint64_t)orow * C + c + i);
+      if (out) store4<float>(out + orow * C + c, o[0], o[1], o[2], o[3]);
+      if (outt) store4<TO>(outt + orow * C + c, o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
+// LayerNorm backward: given dout (grad of `out`, in the remapped row space, with the same output
+// dropout), y, mean, rstd:  dy = LN'(dout) as T (GEMM operand), dgamma/dbeta via f32 atomics.
+// The shortcut gradient is dout itself (caller keeps using it as the residual-stream gradient).
+template <typename TI, int MAXC>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dout, const TI* __restrict__ y,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, TI* __restrict__ dy,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int C,
+                                                            int grp, int grp_stride, int off, float p, const uint32_t* seed,
+                                                            uint32_t tag) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const DropCtx dc = make_drop(seed, tag, p);
+  float dg[MAXC][4], db[MAXC][4];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dg[i][j] = db[i][j] = 0.f;
+  for (long row = (long)blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * wpb) {
+    const TI* yr = y + row * C;
+    const long orow = remap_row(row, grp, grp_stride, off);
+    const float* dor = dout + orow * C;
+    const float mu = mean[row], r = rstd[row];
+    float s1 = 0.f, s2 = 0.f;  // sum(g*do), sum(g*do*xhat)
+    for (int c = lane * 4; c < C; c += 256) {
+      f32x4 v = load4<TI>(yr + c);
+      f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+      f32x4 e = *reinterpret_cast<const f32x4*>(dor + c);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float de = e[i] * drop_mult(dc, (uint64_t)orow * C + c + i);
+        const float xh = (v[i] - mu) * r;
+        s1 += g[i] * de;
+        s2 += g[i] * de * xh;
+      }
+    }
+    s1 = wave_sum(s1) / (float)C;
+    s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int ci = 0; ci < MAXC; ++ci) {
+      const int c = lane * 4 + ci * 256;
+      if (c >= C) continue;
+      f32x4 v = load4<TI>(yr + c);
+      f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+      f32x4 e = *reinterpret_cast<const f32x4*>(dor + c);
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float de = e[i] * drop_mult(dc, (uint64_t)orow * C + c + i);
+        const float xh = (v[i] - mu) * r;
+        o[i] = r * (g[i] * de - s1 - xh * s2);
+        dg[ci][i] += de * xh; db[ci][i] += de;
+      }
+      if (dy) store4<TI>(dy + row * C + c, o[0], o[1], o[2], o[3]);
+    }
+  }
+#pragma unroll
+  for (int ci = 0; ci < MAXC; ++ci) {
+    const int c = lane * 4 + ci * 256;
+    if (c >= C) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (dgamma) atomicAdd(dgamma + c + i, dg[ci][i]);
+      if (dbeta) atomicAdd(dbeta + c + i, db[ci][i]);
+    }
+  }
+}
+
+static inline int norm_grid(int rows) {
+  int g = (rows + 3) / 4;
+  return g < 1 ? 1 : (g > 2048 ? 2048 : g);
+}
+
+}  // namespace klab
+
+using namespace klab;
+
+extern "C" int klab_rmsnorm_fwd(const float* x, const float* w, void* y, int y_dtype, float* y_f32, float* rstd, int rows,
+                                int d, float eps, int grp, int grp_stride, int off, float drop_p,
+                                const uint32_t* seed_dev, uint32_t tag, void* stream) {
+  if (!x || !w || rows < 0 || d <= 0 || (d & 3)) return KLAB_ERR_BADARG;
+  if (rows == 0) return KLAB_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (y_dtype == KLAB_BF16)
+    hipLaunchKernelGGL(rmsnorm_fwd_kernel<bf16_t>, dim3(norm_grid(rows)), dim3(256), 0, s, x, w, (bf16_t*)y, y_f32, rstd, rows, d,
+                       eps, grp, grp_stride, off, drop_p, seed_dev, tag);
+  else
+    hipLaunchKernelGGL(rmsnorm_fwd_kernel<float>, dim3(norm_grid(rows)), dim3(256), 0, s, x, w, (float*)y, y_f32, rstd, rows, d,
+                       eps, grp, grp_stride, off, drop_p, seed_dev, tag);
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+
+extern "C" int klab_rmsnorm_bwd(const float* dy, const float* x, const float* w, const float* rstd, const float* dres,
+                                float* dx, void* dxt, int dxt_dtype, float* dw, int rows, int d, int grp, int grp_stride,
+                                int off, float p_y, uint32_t tag_y, float p_prev, uint32_t tag_prev,
+                                const uint32_t* seed_dev, void* stream) {
+  if (!dy || !x || !w || !rstd || rows < 0 || d <= 0 || (d & 3)) return KLAB_ERR_BADARG;
+  if (d > 256 * 8) return KLAB_ERR_UNSUPPORTED;  // per-lane dw partials cover d <= 2048
+  if (rows == 0) return KLAB_OK;
+  hipStream_t s = (hipStream_t)stream;
+  // fewer, fatter waves: each wave keeps dw partials in registers across its rows
+  int g = (rows + 31) / 32;
+  g = g < 1 ? 1 : (g > 512 ? 512 : g);
+  if (dxt_dtype == KLAB_BF16)
+    hipLaunchKernelGGL((rmsnorm_bwd_kernel<bf16_t, 8>), dim3(g), dim3(256), 0, s, dy, x, w, rstd, dres, dx, (bf16_t*)dxt, dw, rows,
+                       d, grp, grp_stride, off, p_y, tag_y, p_prev, tag_prev, seed_dev);
+  else
+    hipLaunchKernelGGL((rmsnorm_bwd_kernel<float, 8>), dim3(g), dim3(256), 0, s, dy, x, w, rstd, dres, dx, (float*)dxt, dw, rows, d,
+                       grp, grp_stride, off, p_y, tag_y, p_prev, tag_prev, seed_dev);
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+
+extern "C" int klab_layernorm_fwd(const void* y, int y_dtype, const float* gamma, const float* beta, const float* shortcut,
+                                  float* out, void* outt, int outt_dtype, float* mean, float* rstd, int rows, int C,
+                                  float eps, int grp, int grp_stride, int off, float drop_p, const uint32_t* seed_dev,
+                                  uint32_t tag, void* stream) {
+  if (!y || !gamma || !beta || rows < 0 || C <= 0 || (C & 3)) return KLAB_ERR_BADARG;
+  if (rows == 0) return KLAB_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int g = norm_grid(rows);
+#define LN_LAUNCH(TI, TO)                                                                                             \
+  hipLaunchKernelGGL((layernorm_fwd_kernel<TI, TO>), dim3(g), dim3(256), 0, s, (const TI*)y, gamma, beta, shortcut, out, \
+                     (TO*)outt, mean, rstd, rows, C, eps, grp, grp_stride, off, drop_p, seed_dev, tag)
+  if (y_dtype == KLAB_BF16 && outt_dtype == KLAB_BF16) LN_LAUNCH(bf16_t, bf16_t);
+  else if (y_dtype == KLAB_BF16) LN_LAUNCH(bf16_t, float);
+  else if (outt_dtype == KLAB_BF16) LN_LAUNCH(float, bf16_t);
+  else LN_LAUNCH(float, float);
+#undef LN_LAUNCH
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+
+extern "C" int klab_layernorm_bwd(const float* dout, const void* y, int y_dtype, const float* gamma, const float* mean,
+                                  const float* rstd, void* dy, float* dgamma, float* dbeta, int rows, int C, int grp,
+                                  int grp_stride, int off, float drop_p, const uint32_t* seed_dev, uint32_t tag,
+                                  void* stream) {
+  if (!dout || !y || !gamma || !mean || !rstd || rows < 0 || C <= 0 || (C & 3)) return KLAB_ERR_BADARG;
+  if (C > 256 * 8) return KLAB_ERR_UNSUPPORTED;
+  if (rows == 0) return KLAB_OK;
+  hipStream_t s = (hipStream_t)stream;
+  int g = (rows + 31) / 32;
+  g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
+  if (y_dtype == KLAB_BF16)
+    hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, 8>), dim3(g), dim3(256), 0, s, dout, (const bf16_t*)y, gamma, mean, rstd,
+                       (bf16_t*)dy, dgamma, dbeta, rows, C, grp, grp_stride, off, drop_p, seed_dev, tag);
+  else
+    hipLaunchKernelGGL((layernorm_bwd_kernel<float, 8>), dim3(g), dim3(256), 0, s, dout, (const float*)y, gamma, mean, rstd,
+                       (float*)dy, dgamma, dbeta, rows, C, grp, grp_stride, off, drop_p, seed_dev, tag);
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}

@@ -1,0 +1,203 @@
+"""Thin torch-tensor wrappers over the C ABI (one Python function per entry point of klab_mm.h).
+
+Used by the parity tests and by host-side orchestration; tensors only provide device memory
+(`data_ptr()`) and the current HIP stream -- the arithmetic is in libklab_mm.so.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def _seed_ptr(seed):
+    return None if seed is None else seed.data_ptr()
+
+
+def gemm(A, B, C_out, *, M, N, K, a_kmajor=True, b_kmajor=True, lda=None, ldb=None, ldc=None, alpha=1.0,
+         alpha_dev=None, bias=None, act=L.ACT_NONE, aux=None, aux_mode=L.AUX_NONE, aux_scale=1.0, residual=None,
+         drop_p=0.0, seed=None, tag=0, accumulate=False):
+    lib = L.load()
+    a = L.GemmArgs()
+    a.M, a.N, a.K = M, N, K
+    a.dtype = L.dtype_code(A.dtype)
+    assert B.dtype == A.dtype
+    a.A, a.lda, a.a_kmajor = A.data_ptr(), (lda if lda is not None else A.stride(0)), int(a_kmajor)
+    a.B, a.ldb, a.b_kmajor = B.data_ptr(), (ldb if ldb is not None else B.stride(0)), int(b_kmajor)
+    a.C, a.ldc, a.c_dtype = C_out.data_ptr(), (ldc if ldc is not None else C_out.stride(0)), L.dtype_code(C_out.dtype)
+    a.accumulate = int(accumulate)
+    a.alpha = alpha
+    a.alpha_dev = L.ptr(alpha_dev)
+    a.bias = L.ptr(bias)
+    a.act = act
+    a.aux, a.ldaux, a.aux_mode, a.aux_scale = L.ptr(aux), (aux.stride(0) if aux is not None else 0), aux_mode, aux_scale
+    a.residual = L.ptr(residual)
+    a.ldr = residual.stride(0) if residual is not None else 0
+    a.r_dtype = L.dtype_code(residual.dtype) if residual is not None else 0
+    a.drop_p, a.seed_dev, a.drop_tag = drop_p, _seed_ptr(seed), tag
+    L.check(lib.klab_gemm(C.byref(a), L.stream_ptr()), "klab_gemm")
+    return C_out
+
+
+def rmsnorm_fwd(x, w, y=None, y_f32=None, rstd=None, eps=1e-6, grp=0, grp_stride=0, off=0, drop_p=0.0, seed=None, tag=0):
+    lib = L.load()
+    rows, d = x.shape
+    L.check(lib.klab_rmsnorm_fwd(x.data_ptr(), w.data_ptr(), L.ptr(y), L.dtype_code(y.dtype) if y is not None else 0,
+                                 L.ptr(y_f32), L.ptr(rstd), rows, d, eps, grp, grp_stride, off, drop_p, _seed_ptr(seed), tag,
+                                 L.stream_ptr()), "klab_rmsnorm_fwd")
+
+
+def rmsnorm_bwd(dy, x, w, rstd, dres=None, dx=None, dxt=None, dw=None, grp=0, grp_stride=0, off=0, p_y=0.0, tag_y=0,
+                p_prev=0.0, tag_prev=0, seed=None):
+    lib = L.load()
+    rows, d = x.shape
+    L.check(lib.klab_rmsnorm_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), rstd.data_ptr(), L.ptr(dres), L.ptr(dx), L.ptr(dxt),
+                                 L.dtype_code(dxt.dtype) if dxt is not None else 0, L.ptr(dw), rows, d, grp, grp_stride, off,
+                                 p_y, tag_y, p_prev, tag_prev, _seed_ptr(seed), L.stream_ptr()), "klab_rmsnorm_bwd")
+
+
+def layernorm_fwd(y, gamma, beta, shortcut=None, out=None, outt=None, mean=None, rstd=None, eps=1e-5, grp=0, grp_stride=0,
+                  off=0, drop_p=0.0, seed=None, tag=0):
+    lib = L.load()
+    rows, Cc = y.shape
+    L.check(lib.klab_layernorm_fwd(y.data_ptr(), L.dtype_code(y.dtype), gamma.data_ptr(), beta.data_ptr(), L.ptr(shortcut),
+                                   L.ptr(out), L.ptr(outt), L.dtype_code(outt.dtype) if outt is not None else 0, L.ptr(mean),
+                                   L.ptr(rstd), rows, Cc, eps, grp, grp_stride, off, drop_p, _seed_ptr(seed), tag,
+                                   L.stream_ptr()), "klab_layernorm_fwd")
+
+
+def layernorm_bwd(dout, y, gamma, mean, rstd, dy=None, dgamma=None, dbeta=None, grp=0, grp_stride=0, off=0, drop_p=0.0,
+                  seed=None, tag=0):
+    lib = L.load()
+    rows, Cc = y.shape
+    L.check(lib.klab_layernorm_bwd(dout.data_ptr(), y.data_ptr(), L.dtype_code(y.dtype), gamma.data_ptr(), mean.data_ptr(),
+                                   rstd.data_ptr(), L.ptr(dy), L.ptr(dgamma), L.ptr(dbeta), rows, Cc, grp, grp_stride, off,
+                                   drop_p, _seed_ptr(seed), tag, L.stream_ptr()), "klab_layernorm_bwd")
+
+
+def _attn_args(q, k, v, ctx, lse, bias, causal, B, H, Lq, Lk, dk, drop_p, seed, tag, ldq, ldk, ldv, ldo):
+    a = L.AttnArgs()
+    a.dtype = L.dtype_code(q.dtype)
+    a.q, a.ldq = q.data_ptr(), ldq
+    a.k, a.ldk = k.data_ptr(), ldk
+    a.v, a.ldv = v.data_ptr(), ldv
+    a.bias, a.causal = L.ptr(bias), int(causal)
+    a.ctx, a.ldo, a.lse = ctx.data_ptr(), ldo, L.ptr(lse)
+    a.B, a.H, a.Lq, a.Lk, a.dk = B, H, Lq, Lk, dk
+    a.drop_p, a.seed_dev, a.drop_tag = drop_p, _seed_ptr(seed), tag
+    return a
+
+
+def t5_attn_fwd(q, k, v, ctx, lse, *, B, H, Lq, Lk, dk, bias=None, causal=False, drop_p=0.0, seed=None, tag=0,
+                ldq=None, ldk=None, ldv=None, ldo=None):
+    lib = L.load()
+    a = _attn_args(q, k, v, ctx, lse, bias, causal, B, H, Lq, Lk, dk, drop_p, seed, tag,
+                   ldq or q.stride(0), ldk or k.stride(0), ldv or v.stride(0), ldo or ctx.stride(0))
+    L.check(lib.klab_t5_attn_fwd(C.byref(a), L.stream_ptr()), "klab_t5_attn_fwd")
+
+
+def t5_attn_bwd(q, k, v, ctx, lse, dctx, dq, dk_out, dv, *, B, H, Lq, Lk, dk, bias=None, causal=False, dbias=None,
+                drop_p=0.0, seed=None, tag=0, ldq=None, ldk=None, ldv=None, ldo=None, lddo=None, lddq=None, lddk=None,
+                lddv=None):
+    lib = L.load()
+    a = _attn_args(q, k, v, ctx, lse, bias, causal, B, H, Lq, Lk, dk, drop_p, seed, tag,
+                   ldq or q.stride(0), ldk or k.stride(0), ldv or v.stride(0), ldo or ctx.stride(0))
+    a.dctx, a.lddo = dctx.data_ptr(), lddo or dctx.stride(0)
+    a.dq, a.lddq = dq.data_ptr(), lddq or dq.stride(0)
+    a.dk_out, a.lddk = dk_out.data_ptr(), lddk or dk_out.stride(0)
+    a.dv, a.lddv = dv.data_ptr(), lddv or dv.stride(0)
+    a.dbias = L.ptr(dbias)
+    L.check(lib.klab_t5_attn_bwd(C.byref(a), L.stream_ptr()), "klab_t5_attn_bwd")
+
+
+def _swin_args(qkv, ctx, bias, logit_scale, lse, B, R, w, shift, H, Cc):
+    a = L.SwinAttnArgs()
+    a.dtype = L.dtype_code(qkv.dtype)
+    a.qkv, a.ctx, a.bias, a.logit_scale, a.lse = qkv.data_ptr(), ctx.data_ptr(), bias.data_ptr(), logit_scale.data_ptr(), L.ptr(lse)
+    a.B, a.R, a.w, a.shift, a.H, a.C = B, R, w, shift, H, Cc
+    return a
+
+
+def swin_attn_fwd(qkv, ctx, bias, logit_scale, lse=None, *, B, R, w, shift, H, C):
+    lib = L.load()
+    a = _swin_args(qkv, ctx, bias, logit_scale, lse, B, R, w, shift, H, C)
+    L.check(lib.klab_swin_attn_fwd(C_byref(a), L.stream_ptr()), "klab_swin_attn_fwd")
+
+
+def swin_attn_bwd(qkv, ctx, bias, logit_scale, lse, dctx, dqkv, dbias=None, dlogit_scale=None, *, B, R, w, shift, H, C):
+    lib = L.load()
+    a = _swin_args(qkv, ctx, bias, logit_scale, lse, B, R, w, shift, H, C)
+    a.dctx, a.dqkv, a.dbias, a.dlogit_scale = dctx.data_ptr(), dqkv.data_ptr(), L.ptr(dbias), L.ptr(dlogit_scale)
+    L.check(lib.klab_swin_attn_bwd(C_byref(a), L.stream_ptr()), "klab_swin_attn_bwd")
+
+
+C_byref = C.byref
+
+
+def swin_cpb_bias(coords, index, w0, b0, w2, table, bias, hidden=None, *, n, heads):
+    lib = L.load()
+    L.check(lib.klab_swin_cpb_bias(coords.data_ptr(), index.data_ptr(), w0.data_ptr(), b0.data_ptr(), w2.data_ptr(),
+                                   table.data_ptr(), L.ptr(hidden), bias.data_ptr(), coords.shape[0], n, heads, w0.shape[0],
+                                   L.stream_ptr()), "klab_swin_cpb_bias")
+
+
+def ce_fwd(logits, labels, inv_n, loss_row, loss, write_grad=True):
+    lib = L.load()
+    rows, V = logits.shape
+    L.check(lib.klab_ce_fwd(logits.data_ptr(), logits.stride(0), L.dtype_code(logits.dtype), labels.data_ptr(), rows, V,
+                            inv_n.data_ptr(), loss_row.data_ptr(), loss.data_ptr(), int(write_grad), L.stream_ptr()), "klab_ce_fwd")
+
+
+def embed_fwd(ids, table, out, *, shift_right=False, L_seq=1, start_id=0, pad_id=0, drop_p=0.0, seed=None, tag=0, err=None):
+    lib = L.load()
+    rows, d = out.shape
+    L.check(lib.klab_embed_fwd(ids.data_ptr(), int(shift_right), L_seq, start_id, pad_id, table.data_ptr(), table.shape[0],
+                               out.data_ptr(), rows, d, drop_p, _seed_ptr(seed), tag, L.ptr(err), L.stream_ptr()), "klab_embed_fwd")
+
+
+def embed_bwd(ids, dh, dtable, *, shift_right=False, L_seq=1, start_id=0, pad_id=0, drop_p=0.0, seed=None, tag=0):
+    lib = L.load()
+    rows, d = dh.shape
+    L.check(lib.klab_embed_bwd(ids.data_ptr(), int(shift_right), L_seq, start_id, pad_id, dh.data_ptr(), dtable.data_ptr(),
+                               dtable.shape[0], rows, d, drop_p, _seed_ptr(seed), tag, L.stream_ptr()), "klab_embed_bwd")
+
+
+def relbias_fwd(table, bucket, bias):
+    lib = L.load()
+    H, Lq, Lk = bias.shape
+    L.check(lib.klab_relbias_fwd(table.data_ptr(), bucket.data_ptr(), bias.data_ptr(), H, Lq, Lk, L.stream_ptr()), "klab_relbias_fwd")
+
+
+def relbias_bwd(dbias, bucket, dtable):
+    lib = L.load()
+    H, Lq, Lk = dbias.shape
+    L.check(lib.klab_relbias_bwd(dbias.data_ptr(), bucket.data_ptr(), dtable.data_ptr(), H, Lq, Lk, dtable.shape[0],
+                                 L.stream_ptr()), "klab_relbias_bwd")
+
+
+def im2col_patch(pixels, out, P):
+    lib = L.load()
+    B, Cin, Himg, _ = pixels.shape
+    L.check(lib.klab_im2col_patch(pixels.data_ptr(), out.data_ptr(), L.dtype_code(out.dtype), B, Cin, Himg, P, L.stream_ptr()),
+            "klab_im2col_patch")
+
+
+def merge_gather(x, out, *, B, R, C):
+    lib = L.load()
+    L.check(lib.klab_merge_gather(x.data_ptr(), out.data_ptr(), L.dtype_code(out.dtype), B, R, C, L.stream_ptr()), "klab_merge_gather")
+
+
+def merge_scatter(dm, dx, *, B, R, C):
+    lib = L.load()
+    L.check(lib.klab_merge_scatter(dm.data_ptr(), dx.data_ptr(), B, R, C, L.stream_ptr()), "klab_merge_scatter")
+
+
+def colsum(dy, out):
+    lib = L.load()
+    M, N = dy.shape
+    L.check(lib.klab_colsum(dy.data_ptr(), dy.stride(0), L.dtype_code(dy.dtype), M, N, out.data_ptr(), L.stream_ptr()), "klab_colsum")
+
+
+def convert(x, y, scale=1.0):
+    lib = L.load()
+    L.check(lib.klab_convert(x.data_ptr(), y.data_ptr(), L.dtype_code(y.dtype), x.numel(), scale, L.stream_ptr()), "klab_convert")
