@@ -157,6 +157,66 @@ int klab_colsum(const void* dy, long ld, int dtype, int M, int N, float* out, vo
 int klab_convert(const float* x, void* y, int dtype, long n, float scale, void* stream);
 int klab_add_f32(float* y, const float* x, long n, void* stream);
 
+int klab_gelu_fwd(const void* x, void* y, int dtype, long n, void* stream);
+int klab_swin_cpb_bias_bwd(const float* dbias, const float* bias, const int* index, const float* coords, const float* hidden,
+                           const float* w0, const float* w2, float* dtable, float* dw0, float* db0, float* dw2, int ntab, int n,
+                           int heads, int nhidden, void* stream);
+
+/* ==== the whole path: MyModel.forward + backward (ref/models/model.py:19-26, ref/train.py:58-62) ====
+ * The engine is a host-side plan over the kernels above.  It owns no device memory: parameters are
+ * the caller's fp32 tensors (named exactly like the HuggingFace state dict), activations
+ * live in one caller-provided workspace, gradients are written into caller-provided flat f32 buffers
+ * at the offsets published by klab_engine_param_info.  model index: 0 = Swin-V2 image_model,
+ * 1 = frozen language_model (T5 encoder), 2 = transformer (T5ForConditionalGeneration).            */
+typedef struct klab_swin_cfg {  /* HF/swinv2cfg:56-73 */
+  int image_size, patch, in_ch, embed_dim, n_stages;
+  int depths[8], heads[8];
+  int window;
+  int pretrained_window[8];
+  int mlp_ratio, qkv_bias;
+  float ln_eps;
+} klab_swin_cfg;
+typedef struct klab_t5_cfg {    /* HF/t5cfg:44-62,82-83 */
+  int vocab, d_model, d_kv, n_heads, d_ff, n_layers, n_dec_layers, rel_buckets, rel_max_dist;
+  float dropout, ln_eps;
+  int start_id, pad_id, scale_decoder_outputs;
+} klab_t5_cfg;
+typedef struct klab_model_cfg {
+  klab_swin_cfg swin;
+  klab_t5_cfg lang, main;
+  int dtype;      /* KLAB_F32 parity mode | KLAB_BF16 */
+  int train_swin; /* args.image_model_train (ref/models/model.py:15) */
+} klab_model_cfg;
+typedef struct klab_engine klab_engine;
+
+klab_engine* klab_engine_create(const klab_model_cfg* cfg); /* NULL on an invalid config (e.g. Swin width != d_model:
+                                                               the reference raises at its torch.cat, model.py:23) */
+void klab_engine_destroy(klab_engine* e);
+int klab_engine_num_params(const klab_engine* e, int model);
+int klab_engine_param_info(const klab_engine* e, int model, int i, char* name, int name_cap, long* shape4, int* ndim,
+                           long* grad_off /* element offset in the model's flat grad buffer, -1 = frozen */);
+long klab_engine_grad_elems(const klab_engine* e, int model);
+/* backward segment -> (model, offset, length) of the flat-grad slice that is final when it returns */
+int klab_engine_segment(const klab_engine* e, int seg, int* model, long* off, long* len);
+size_t klab_engine_workspace_bytes(klab_engine* e, int B, int Ls, int Lt);
+/* *_params: host arrays of device pointers in klab_engine_param_info order.  *_bucket: int32 device
+ * arrays [L*L] of T5 relative-position buckets (HF/t5:216-262, computed by the host exactly as the
+ * reference does).  swin_coords[s] / swin_index[s]: per-stage CPB tables (HF/swinv2:457-492).      */
+int klab_engine_bind(klab_engine* e, int B, int Ls, int Lt, void* workspace, size_t ws_bytes, const void* const* swin_params,
+                     const void* const* lang_params, const void* const* main_params, float* main_grads, float* swin_grads,
+                     const int* lang_bucket, const int* enc_bucket, const int* dec_bucket, const void* const* swin_coords,
+                     const void* const* swin_index, void* stream);
+/* pixels [B,3,H,W] f32, src_ids [B,Ls] / tgt_ids [B,Lt] int64 (device).  training: T5 dropout on
+ * (model.module.transformer.train(), ref/train.py:52).  The loss lands in *klab_engine_loss_ptr.  */
+int klab_engine_forward(klab_engine* e, const float* pixels, const long long* src_ids, const long long* tgt_ids, int training,
+                        uint32_t seed, int want_grad, void* stream);
+/* segment 0: LM head + decoder + tied embedding; 1: encoder; 2: Swin (no-op unless train_swin).
+ * dloss_dev: device scalar d(objective)/d(loss) (NULL = 1).                                       */
+int klab_engine_backward(klab_engine* e, int segment, const float* dloss_dev, void* stream);
+const float* klab_engine_loss_ptr(const klab_engine* e);
+const int* klab_engine_err_ptr(const klab_engine* e);
+const void* klab_engine_buffer(const klab_engine* e, const char* name, long* rows, long* cols, int* dtype);
+
 #ifdef __cplusplus
 }
 #endif

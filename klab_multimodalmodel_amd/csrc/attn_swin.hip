@@ -322,6 +322,36 @@ __global__ void cpb_gather_kernel(const float* __restrict__ table, const int* __
   bias[idx] = 16.f / (1.f + __expf(-v));
 }
 
+
+// CPB backward: dbias[H,n,n] -> d table -> MLP weight grads (accumulated into zeroed buffers).
+__global__ void cpb_dtable_kernel(const float* __restrict__ dbias, const float* __restrict__ bias, const int* __restrict__ index,
+                                  float* __restrict__ dtable, int H, int nn) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)H * nn) return;
+  const int h = idx / nn, ij = idx % nn;
+  const float bv = bias[idx];                       // 16*sigmoid(t)
+  atomicAdd(dtable + index[ij] * H + h, dbias[idx] * bv * (1.f - bv * 0.0625f));
+}
+__global__ __launch_bounds__(256) void cpb_mlp_bwd_kernel(const float* __restrict__ dtable, const float* __restrict__ coords,
+                                                          const float* __restrict__ hidden, const float* __restrict__ w2, float* __restrict__ dw0,
+                                                          float* __restrict__ db0, float* __restrict__ dw2, int ntab, int H, int nh) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;  // hidden unit
+  if (j >= nh) return;
+  for (int h = 0; h < H; ++h) {
+    float s = 0.f;
+    for (int t = 0; t < ntab; ++t) s += dtable[t * H + h] * hidden[(long)t * nh + j];
+    dw2[h * nh + j] += s;
+  }
+  float a0 = 0.f, a1 = 0.f, ab = 0.f;
+  for (int t = 0; t < ntab; ++t) {
+    if (hidden[(long)t * nh + j] <= 0.f) continue;  // ReLU
+    float g = 0.f;
+    for (int h = 0; h < H; ++h) g += dtable[t * H + h] * w2[h * nh + j];
+    a0 += g * coords[t * 2]; a1 += g * coords[t * 2 + 1]; ab += g;
+  }
+  dw0[j * 2] += a0; dw0[j * 2 + 1] += a1; db0[j] += ab;
+}
+
 }  // namespace klab
 
 using namespace klab;
@@ -399,6 +429,22 @@ extern "C" int klab_swin_cpb_bias(const float* coords, const int* index, const f
   KLAB_LAUNCH_CHECK();
   const long tot = (long)heads * n * n;
   hipLaunchKernelGGL(cpb_gather_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, table, index, bias, heads, n * n);
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+
+extern "C" int klab_swin_cpb_bias_bwd(const float* dbias, const float* bias, const int* index, const float* coords, const float* hidden,
+                                      const float* w0, const float* w2, float* dtable, float* dw0, float* db0, float* dw2, int ntab, int n,
+                                      int heads, int nhidden, void* stream) {
+  (void)w0;
+  if (!dbias || !bias || !index || !coords || !hidden || !w2 || !dtable || !dw0 || !db0 || !dw2) return KLAB_ERR_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(dtable, 0, (size_t)ntab * heads * 4, s);
+  if (e != hipSuccess) return (int)e;
+  const long tot = (long)heads * n * n;
+  hipLaunchKernelGGL(cpb_dtable_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, dbias, bias, index, dtable, heads, n * n);
+  KLAB_LAUNCH_CHECK();
+  hipLaunchKernelGGL(cpb_mlp_bwd_kernel, dim3((nhidden + 255) / 256), dim3(256), 0, s, dtable, coords, hidden, w2, dw0, db0, dw2, ntab, heads, nhidden);
   KLAB_LAUNCH_CHECK();
   return KLAB_OK;
 }

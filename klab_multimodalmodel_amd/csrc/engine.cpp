@@ -1,0 +1,1040 @@
+// klab_engine: the whole MyModel.forward / backward (ref/models/model.py:19-26 + autograd) as ONE
+// native launch sequence on one HIP stream.
+//
+// The reference drives this path from Python through three HuggingFace modules, ~2,000 ATen kernel
+// launches per step with a host round trip each; here the host side is a C++ plan that, for a fixed
+// (B, Ls, Lt), knows every buffer in one caller-owned workspace and issues the hand-written kernels
+// back to back (no allocation, no sync => the sequence is hipGraph-capturable).
+//   forward : frozen T5 encoder over src ids (ref model.py:20-21)  ->  rows [N_img, Le) of the encoder
+//             input;  Swin-V2 over pixels (model.py:22) -> rows [0, N_img)  (the torch.cat of
+//             model.py:23 is a row remap in the two final norms);  T5 encoder + decoder + tied LM head
+//             + cross-entropy (model.py:26, HF/t5:1009-1054).
+//   backward: segments 0 (LM head + decoder + shared embedding), 1 (encoder), 2 (Swin, only when
+//             --image_model_train); the caller may launch a gradient all-reduce per segment while the
+//             next one runs (DDP overlap, ref/train.py:26,62).
+// Parameters stay caller-owned fp32 tensors named exactly like the HuggingFace state dict
+// (SURVEY §8b); the engine publishes (name, shape, grad offset) so the host mirrors that schema.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "klab_mm.h"
+
+namespace {
+
+#define RC(x)                 \
+  do {                        \
+    int rc__ = (x);           \
+    if (rc__ != 0) return rc__; \
+  } while (0)
+
+struct ParamInfo {
+  std::string name;
+  std::vector<long> shape;
+  long numel = 0;
+  long grad_off = -1;   // element offset in the model's flat f32 grad buffer, -1 = frozen
+  long warena_off = -1; // element offset in the compute-dtype weight arena (-1: used in fp32 directly)
+  long farena_off = -1; // element offset in the f32 side arena (fused bias vectors)
+};
+
+struct T5LayerIdx { int q, k, v, o, relb, ln0, cq, ck, cv, co, ln1, wi, wo, ln2; };
+struct T5Idx { int shared; std::vector<T5LayerIdx> enc, dec; int enc_final, dec_final; };
+struct SwinBlockIdx { int ls, c0w, c0b, c2w, qw, qb, kw, vw, vb, pw, pb, ln1w, ln1b, f1w, f1b, f2w, f2b, ln2w, ln2b; };
+struct SwinStageIdx { std::vector<SwinBlockIdx> blk; int redw, mnw, mnb; };
+struct SwinIdx { int pew, peb, penw, penb; std::vector<SwinStageIdx> st; int lnw, lnb; };
+
+struct T5LayerBufs {
+  void *xn1, *qkv, *ctx; float *lse, *rstd1;
+  void *xn2, *qc, *ctx2; float *lse2, *rstd2;
+  void *xn3, *hmid; float* rstd3;
+};
+struct T5StackBufs {
+  std::vector<float*> h;
+  std::vector<T5LayerBufs> L;
+  void* out_t = nullptr; float* rstd_f = nullptr;
+  float* bias = nullptr; float* dbias = nullptr; const int* bucket = nullptr;
+  int M = 0, Lseq = 0;
+};
+struct SwinBlockBufs {
+  float* x_in; void* xt_in;   // block input (f32 stream + dtype copy)
+  void *qkv, *ctx, *po; float *lse, *mean1, *rstd1; float* h1; void* h1t;
+  void *z, *a, *fo; float *mean2, *rstd2; float* h2; void* h2t;
+  float *bias, *table, *hidden;
+  int R, w, shift, H, C; long M;
+};
+struct SwinStageBufs { std::vector<SwinBlockBufs> blk; void *mg, *mo; float *mmean, *mrstd; float* xm; void* xmt; };
+
+struct Bump {
+  char* base; size_t off = 0;
+  explicit Bump(void* b) : base((char*)b) {}
+  void* take(size_t bytes) {
+    off = (off + 255) & ~(size_t)255;
+    void* p = base ? base + off : nullptr;
+    off += bytes;
+    return p;
+  }
+};
+
+}  // namespace
+
+struct klab_engine {
+  klab_model_cfg cfg;
+  std::vector<ParamInfo> P[3];  // 0 swin, 1 lang, 2 main
+  SwinIdx si; T5Idx li, mi;
+  long grad_elems[3] = {0, 0, 0};
+  long seg_zero_off[3] = {0, 0, 0}, seg_zero_len[3] = {0, 0, 0};  // per backward segment: small atomically-accumulated grads
+  long seg_off[3] = {0, 0, 0}, seg_len[3] = {0, 0, 0};            // per segment: extent in its flat grad buffer
+  long warena_elems = 0, farena_elems = 0;
+  long kvall_w_off = -1, kvall_g_off = -1;  // decoder cross k|v of all layers (weight arena / grad offsets)
+  // ---- bound state ----
+  bool bound = false;
+  int B = 0, Ls = 0, Lt = 0, Le = 0, Nimg = 0;
+  size_t es = 4;
+  std::vector<const float*> W[3];
+  float* G[3] = {nullptr, nullptr, nullptr};
+  void* warena = nullptr; float* farena = nullptr;
+  void* cast_desc = nullptr; int n_cast = 0; long cast_total4 = 0;
+  void* fcast_desc = nullptr; int n_fcast = 0; long fcast_total4 = 0;
+  uint32_t* seed_dev = nullptr; int* err_dev = nullptr;
+  const int *enc_bucket = nullptr, *dec_bucket = nullptr, *lang_bucket = nullptr;
+  std::vector<const float*> swin_coords; std::vector<const int*> swin_index; std::vector<int> swin_ntab;
+  T5StackBufs lang, enc, dec;
+  // lang scratch (no grad => reused across layers)
+  void* kv_all = nullptr; void* dkv_all = nullptr;
+  void* logits = nullptr; float *loss_row = nullptr, *inv_n = nullptr, *loss = nullptr;
+  float *dh_a = nullptr, *dh_b = nullptr, *dxn = nullptr, *denc = nullptr;
+  void *dy_t = nullptr, *dctx = nullptr, *dqkv = nullptr, *dhmid = nullptr, *dqc = nullptr;
+  void *cols = nullptr, *pe_out = nullptr; float *pe_mean = nullptr, *pe_rstd = nullptr; float* x0 = nullptr; void* x0t = nullptr;
+  std::vector<SwinStageBufs> sw;
+  float *sw_fmean = nullptr, *sw_frstd = nullptr;
+  // swin backward scratch
+  float *sdh_a = nullptr, *sdh_b = nullptr, *sdm = nullptr; void *sdy = nullptr, *sdctx = nullptr, *sdqkv = nullptr, *sda = nullptr;
+  float *sdbias = nullptr, *sdtable = nullptr;
+  float p_train = 0.f;   // dropout prob in effect for the last forward (0 in eval)
+  const long long* last_tgt = nullptr;
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// parameter tables (names = HuggingFace state-dict keys)
+// ------------------------------------------------------------------------------------------------
+int add_param(std::vector<ParamInfo>& v, const std::string& name, std::vector<long> shape) {
+  ParamInfo p;
+  p.name = name; p.shape = shape; p.numel = 1;
+  for (long s : shape) p.numel *= s;
+  v.push_back(p);
+  return (int)v.size() - 1;
+}
+
+void build_t5_params(const klab_t5_cfg& c, bool encoder_only, std::vector<ParamInfo>& v, T5Idx& ix) {
+  const long d = c.d_model, inner = (long)c.n_heads * c.d_kv, ff = c.d_ff;
+  ix.shared = add_param(v, "shared.weight", {c.vocab, d});
+  auto stack = [&](const char* pre, int nl, bool dec, std::vector<T5LayerIdx>& L, int& fin) {
+    for (int i = 0; i < nl; ++i) {
+      T5LayerIdx l;
+      memset(&l, -1, sizeof(l));
+      std::string bp = std::string(pre) + "block." + std::to_string(i) + ".";
+      std::string ap = bp + "layer.0.SelfAttention.";
+      l.q = add_param(v, ap + "q.weight", {inner, d});
+      l.k = add_param(v, ap + "k.weight", {inner, d});
+      l.v = add_param(v, ap + "v.weight", {inner, d});
+      l.o = add_param(v, ap + "o.weight", {d, inner});
+      if (i == 0) l.relb = add_param(v, ap + "relative_attention_bias.weight", {c.rel_buckets, c.n_heads});
+      l.ln0 = add_param(v, bp + "layer.0.layer_norm.weight", {d});
+      int li = 1;
+      if (dec) {
+        std::string cp = bp + "layer.1.EncDecAttention.";
+        l.cq = add_param(v, cp + "q.weight", {inner, d});
+        l.ck = add_param(v, cp + "k.weight", {inner, d});
+        l.cv = add_param(v, cp + "v.weight", {inner, d});
+        l.co = add_param(v, cp + "o.weight", {d, inner});
+        l.ln1 = add_param(v, bp + "layer.1.layer_norm.weight", {d});
+        li = 2;
+      }
+      std::string fp = bp + "layer." + std::to_string(li) + ".";
+      l.wi = add_param(v, fp + "DenseReluDense.wi.weight", {ff, d});
+      l.wo = add_param(v, fp + "DenseReluDense.wo.weight", {d, ff});
+      l.ln2 = add_param(v, fp + "layer_norm.weight", {d});
+      L.push_back(l);
+    }
+    fin = add_param(v, std::string(pre) + "final_layer_norm.weight", {d});
+  };
+  if (!encoder_only) stack("decoder.", c.n_dec_layers, true, ix.dec, ix.dec_final);
+  stack("encoder.", c.n_layers, false, ix.enc, ix.enc_final);
+}
+
+void build_swin_params(const klab_swin_cfg& c, std::vector<ParamInfo>& v, SwinIdx& ix) {
+  const long C0 = c.embed_dim;
+  ix.pew = add_param(v, "embeddings.patch_embeddings.projection.weight", {C0, c.in_ch, c.patch, c.patch});
+  ix.peb = add_param(v, "embeddings.patch_embeddings.projection.bias", {C0});
+  ix.penw = add_param(v, "embeddings.norm.weight", {C0});
+  ix.penb = add_param(v, "embeddings.norm.bias", {C0});
+  for (int s = 0; s < c.n_stages; ++s) {
+    SwinStageIdx st;
+    const long C = C0 << s, H = c.heads[s], F = (long)c.mlp_ratio * C;
+    for (int b = 0; b < c.depths[s]; ++b) {
+      SwinBlockIdx k;
+      memset(&k, -1, sizeof(k));
+      std::string bp = "encoder.layers." + std::to_string(s) + ".blocks." + std::to_string(b) + ".";
+      std::string sp = bp + "attention.self.";
+      k.ls = add_param(v, sp + "logit_scale", {H, 1, 1});
+      k.c0w = add_param(v, sp + "continuous_position_bias_mlp.0.weight", {512, 2});
+      k.c0b = add_param(v, sp + "continuous_position_bias_mlp.0.bias", {512});
+      k.c2w = add_param(v, sp + "continuous_position_bias_mlp.2.weight", {H, 512});
+      k.qw = add_param(v, sp + "query.weight", {C, C});
+      if (c.qkv_bias) k.qb = add_param(v, sp + "query.bias", {C});
+      k.kw = add_param(v, sp + "key.weight", {C, C});
+      k.vw = add_param(v, sp + "value.weight", {C, C});
+      if (c.qkv_bias) k.vb = add_param(v, sp + "value.bias", {C});
+      k.pw = add_param(v, bp + "attention.output.dense.weight", {C, C});
+      k.pb = add_param(v, bp + "attention.output.dense.bias", {C});
+      k.ln1w = add_param(v, bp + "layernorm_before.weight", {C});
+      k.ln1b = add_param(v, bp + "layernorm_before.bias", {C});
+      k.f1w = add_param(v, bp + "intermediate.dense.weight", {F, C});
+      k.f1b = add_param(v, bp + "intermediate.dense.bias", {F});
+      k.f2w = add_param(v, bp + "output.dense.weight", {C, F});
+      k.f2b = add_param(v, bp + "output.dense.bias", {C});
+      k.ln2w = add_param(v, bp + "layernorm_after.weight", {C});
+      k.ln2b = add_param(v, bp + "layernorm_after.bias", {C});
+      st.blk.push_back(k);
+    }
+    st.redw = st.mnw = st.mnb = -1;
+    if (s < c.n_stages - 1) {
+      std::string dp = "encoder.layers." + std::to_string(s) + ".downsample.";
+      st.redw = add_param(v, dp + "reduction.weight", {2 * C, 4 * C});
+      st.mnw = add_param(v, dp + "norm.weight", {2 * C});
+      st.mnb = add_param(v, dp + "norm.bias", {2 * C});
+    }
+    ix.st.push_back(st);
+  }
+  const long Cl = C0 << (c.n_stages - 1);
+  ix.lnw = add_param(v, "layernorm.weight", {Cl});
+  ix.lnb = add_param(v, "layernorm.bias", {Cl});
+}
+
+inline long pad8(long n) { return (n + 7) & ~7L; }
+
+// weight-arena (compute dtype) offsets; q|k|v and the decoder's cross k|v of ALL layers are adjacent
+void plan_arenas(klab_engine* e) {
+  long w = 0, f = 0;
+  auto putw = [&](std::vector<ParamInfo>& v, int i) { if (i >= 0) { v[i].warena_off = w; w += pad8(v[i].numel); } };
+  auto t5 = [&](std::vector<ParamInfo>& v, T5Idx& ix, bool is_main) {
+    putw(v, ix.shared);  // tied LM head operand (and nothing else: embeddings are gathered from the f32 master)
+    for (auto& l : ix.dec) { putw(v, l.q); putw(v, l.k); putw(v, l.v); putw(v, l.o); putw(v, l.cq); putw(v, l.co); putw(v, l.wi); putw(v, l.wo); }
+    if (is_main && !ix.dec.empty()) {
+      e->kvall_w_off = w;
+      for (auto& l : ix.dec) { putw(v, l.ck); putw(v, l.cv); }
+    }
+    for (auto& l : ix.enc) { putw(v, l.q); putw(v, l.k); putw(v, l.v); putw(v, l.o); putw(v, l.wi); putw(v, l.wo); }
+  };
+  t5(e->P[2], e->mi, true);
+  {  // lang: encoder only; shared is gathered in f32 => no arena copy
+    auto& v = e->P[1];
+    for (auto& l : e->li.enc) { putw(v, l.q); putw(v, l.k); putw(v, l.v); putw(v, l.o); putw(v, l.wi); putw(v, l.wo); }
+  }
+  {
+    auto& v = e->P[0];
+    putw(v, e->si.pew);
+    for (auto& st : e->si.st) {
+      for (auto& k : st.blk) {
+        putw(v, k.qw); putw(v, k.kw); putw(v, k.vw); putw(v, k.pw); putw(v, k.f1w); putw(v, k.f2w);
+        // fused q|k|v bias vector [3C] in the f32 side arena (k has no bias: its slot stays zero)
+        const long C = v[k.qw].shape[0];
+        if (k.qb >= 0) { v[k.qb].farena_off = f; v[k.vb].farena_off = f + 2 * C; }
+        f += 3 * C;
+      }
+      putw(v, st.redw);
+    }
+  }
+  e->warena_elems = w;
+  e->farena_elems = f > 0 ? f : 8;
+}
+
+// flat gradient layouts.  main: segment 0 = [small decoder params | shared | decoder weights | cross k|v of
+// all layers], segment 1 = [small encoder params | encoder weights].  swin: segment 2 = [small | weights].
+void plan_grads(klab_engine* e) {
+  {
+    auto& v = e->P[2];
+    long g = 0;
+    auto put = [&](int i) { if (i >= 0) { v[i].grad_off = g; g += pad8(v[i].numel); } };
+    e->seg_off[0] = 0; e->seg_zero_off[0] = 0;
+    for (auto& l : e->mi.dec) { put(l.ln0); put(l.ln1); put(l.ln2); put(l.relb); }
+    put(e->mi.dec_final);
+    e->seg_zero_len[0] = g;
+    put(e->mi.shared);
+    for (auto& l : e->mi.dec) { put(l.q); put(l.k); put(l.v); put(l.o); put(l.cq); put(l.co); put(l.wi); put(l.wo); }
+    e->kvall_g_off = g;
+    for (auto& l : e->mi.dec) { put(l.ck); put(l.cv); }
+    e->seg_len[0] = g;
+    e->seg_off[1] = g; e->seg_zero_off[1] = g;
+    for (auto& l : e->mi.enc) { put(l.ln0); put(l.ln2); put(l.relb); }
+    put(e->mi.enc_final);
+    e->seg_zero_len[1] = g - e->seg_off[1];
+    for (auto& l : e->mi.enc) { put(l.q); put(l.k); put(l.v); put(l.o); put(l.wi); put(l.wo); }
+    e->seg_len[1] = g - e->seg_off[1];
+    e->grad_elems[2] = g;
+  }
+  if (e->cfg.train_swin) {
+    auto& v = e->P[0];
+    long g = 0;
+    auto put = [&](int i) { if (i >= 0) { v[i].grad_off = g; g += pad8(v[i].numel); } };
+    put(e->si.peb); put(e->si.penw); put(e->si.penb); put(e->si.lnw); put(e->si.lnb);
+    for (auto& st : e->si.st) {
+      for (auto& k : st.blk) {
+        put(k.ls); put(k.c0w); put(k.c0b); put(k.c2w); put(k.qb); put(k.vb); put(k.pb); put(k.ln1w); put(k.ln1b);
+        put(k.f1b); put(k.f2b); put(k.ln2w); put(k.ln2b);
+      }
+      put(st.mnw); put(st.mnb);
+    }
+    e->seg_zero_off[2] = 0; e->seg_zero_len[2] = g;
+    put(e->si.pew);
+    for (auto& st : e->si.st) {
+      for (auto& k : st.blk) { put(k.qw); put(k.kw); put(k.vw); put(k.pw); put(k.f1w); put(k.f2w); }
+      put(st.redw);
+    }
+    e->seg_off[2] = 0; e->seg_len[2] = g;
+    e->grad_elems[0] = g;
+  }
+}
+
+inline uint32_t tag_of(int stack, int layer, int site) { return ((uint32_t)stack << 16) | ((uint32_t)layer << 4) | (uint32_t)site; }
+enum { SITE_IN = 0, SITE_PROB = 1, SITE_ATTN_OUT = 2, SITE_XPROB = 3, SITE_XOUT = 4, SITE_MID = 5, SITE_FFN_OUT = 6, SITE_FINAL = 7 };
+enum { STACK_LANG = 0, STACK_ENC = 1, STACK_DEC = 2 };
+
+// ------------------------------------------------------------------------------------------------
+// workspace plan
+// ------------------------------------------------------------------------------------------------
+void plan_t5_stack(Bump& b, const klab_t5_cfg& c, int nl, bool dec, bool save, int M, int B, int L, size_t es, T5StackBufs& s,
+                   int Lkv) {
+  const long d = c.d_model, inner = (long)c.n_heads * c.d_kv, ff = c.d_ff, H = c.n_heads;
+  s.M = M; s.Lseq = L;
+  const int nsub = dec ? 3 : 2;
+  const int nh = save ? nsub * nl + 1 : 2;
+  s.h.resize(nsub * nl + 1);
+  std::vector<float*> pool(nh);
+  for (int i = 0; i < nh; ++i) pool[i] = (float*)b.take((size_t)M * d * 4);
+  for (int i = 0; i <= nsub * nl; ++i) s.h[i] = save ? pool[i] : pool[i & 1];
+  s.L.resize(nl);
+  T5LayerBufs shared_l{};
+  for (int i = 0; i < nl; ++i) {
+    T5LayerBufs l{};
+    if (save || i == 0) {
+      l.xn1 = b.take((size_t)M * d * es); l.qkv = b.take((size_t)M * 3 * inner * es); l.ctx = b.take((size_t)M * inner * es);
+      l.lse = (float*)b.take((size_t)B * H * L * 4); l.rstd1 = (float*)b.take((size_t)M * 4);
+      if (dec) {
+        l.xn2 = b.take((size_t)M * d * es); l.qc = b.take((size_t)M * inner * es); l.ctx2 = b.take((size_t)M * inner * es);
+        l.lse2 = (float*)b.take((size_t)B * H * L * 4); l.rstd2 = (float*)b.take((size_t)M * 4);
+      }
+      l.xn3 = b.take((size_t)M * d * es); l.hmid = b.take((size_t)M * ff * es); l.rstd3 = (float*)b.take((size_t)M * 4);
+      shared_l = l;
+    } else {
+      l = shared_l;
+    }
+    s.L[i] = l;
+  }
+  s.out_t = b.take((size_t)M * d * es);
+  s.rstd_f = (float*)b.take((size_t)M * 4);
+  s.bias = (float*)b.take((size_t)H * L * L * 4);
+  s.dbias = save ? (float*)b.take((size_t)H * L * L * 4) : nullptr;
+  (void)Lkv;
+}
+
+size_t plan_workspace(klab_engine* e, void* base, int B, int Ls, int Lt) {
+  Bump b(base);
+  const klab_model_cfg& c = e->cfg;
+  const size_t es = c.dtype == KLAB_BF16 ? 2 : 4;
+  e->es = es;
+  const int R0 = c.swin.image_size / c.swin.patch;
+  const int Rl = R0 >> (c.swin.n_stages - 1);
+  const int Nimg = Rl * Rl, Le = Nimg + Ls;
+  e->B = B; e->Ls = Ls; e->Lt = Lt; e->Le = Le; e->Nimg = Nimg;
+  const long d = c.main.d_model, inner = (long)c.main.n_heads * c.main.d_kv, ff = c.main.d_ff;
+  const long Me = (long)B * Le, Md = (long)B * Lt;
+  const int nld = c.main.n_dec_layers;
+
+  e->seed_dev = (uint32_t*)b.take(256);
+  e->err_dev = (int*)((char*)e->seed_dev + 64);
+  e->inv_n = (float*)((char*)e->seed_dev + 128);
+  e->loss = (float*)((char*)e->seed_dev + 192);
+  e->warena = b.take((size_t)e->warena_elems * es);
+  e->farena = (float*)b.take((size_t)e->farena_elems * 4);
+  e->cast_desc = b.take(sizeof(long) * 3 * (e->P[0].size() + e->P[1].size() + e->P[2].size() + 1));
+  e->fcast_desc = b.take(sizeof(long) * 3 * (e->P[0].size() + 1));
+
+  plan_t5_stack(b, c.lang, c.lang.n_layers, false, false, B * Ls, B, Ls, es, e->lang, 0);
+  plan_t5_stack(b, c.main, c.main.n_layers, false, true, (int)Me, B, Le, es, e->enc, 0);
+  plan_t5_stack(b, c.main, nld, true, true, (int)Md, B, Lt, es, e->dec, Le);
+  e->kv_all = b.take((size_t)Me * nld * 2 * inner * es);
+  e->dkv_all = b.take((size_t)Me * nld * 2 * inner * es);
+  e->logits = b.take((size_t)Md * c.main.vocab * es);
+  e->loss_row = (float*)b.take((size_t)Md * 4);
+  const long Mx = Me > Md ? Me : Md;
+  e->dh_a = (float*)b.take((size_t)Mx * d * 4);
+  e->dh_b = (float*)b.take((size_t)Mx * d * 4);
+  e->dxn = (float*)b.take((size_t)Mx * d * 4);
+  e->denc = (float*)b.take((size_t)Me * d * 4);
+  e->dy_t = b.take((size_t)Mx * d * es);
+  e->dctx = b.take((size_t)Mx * inner * es);
+  e->dqkv = b.take((size_t)Mx * 3 * inner * es);
+  e->dhmid = b.take((size_t)Mx * ff * es);
+  e->dqc = b.take((size_t)Md * inner * es);
+
+  // ---- Swin ----
+  const klab_swin_cfg& s = c.swin;
+  const long T0 = (long)R0 * R0, M0 = (long)B * T0, K0 = (long)s.in_ch * s.patch * s.patch, C0 = s.embed_dim;
+  e->cols = b.take((size_t)M0 * K0 * es);
+  e->pe_out = b.take((size_t)M0 * C0 * es);
+  e->pe_mean = (float*)b.take((size_t)M0 * 4); e->pe_rstd = (float*)b.take((size_t)M0 * 4);
+  e->x0 = (float*)b.take((size_t)M0 * C0 * 4); e->x0t = b.take((size_t)M0 * C0 * es);
+  e->sw.assign(s.n_stages, SwinStageBufs());
+  long maxMC = M0 * C0;
+  for (int st = 0; st < s.n_stages; ++st) {
+    const int R = R0 >> st;
+    const long C = C0 << st, M = (long)B * R * R, F = (long)s.mlp_ratio * C;
+    const int H = s.heads[st];
+    const int w = R < s.window ? R : s.window;
+    const int n = w * w, nW = (R / (w > 0 ? w : 1)) * (R / (w > 0 ? w : 1));
+    const int ntab = (2 * w - 1) * (2 * w - 1);
+    if (M * C > maxMC) maxMC = M * C;
+    SwinStageBufs& sb = e->sw[st];
+    sb.blk.resize(s.depths[st]);
+    for (int k = 0; k < s.depths[st]; ++k) {
+      SwinBlockBufs& q = sb.blk[k];
+      q.R = R; q.w = w; q.H = H; q.C = (int)C; q.M = M;
+      q.shift = (k % 2 == 0 || R <= w) ? 0 : s.window / 2;
+      q.qkv = b.take((size_t)M * 3 * C * es); q.ctx = b.take((size_t)M * C * es); q.po = b.take((size_t)M * C * es);
+      q.lse = (float*)b.take((size_t)B * nW * H * n * 4);
+      q.mean1 = (float*)b.take((size_t)M * 4); q.rstd1 = (float*)b.take((size_t)M * 4);
+      q.h1 = (float*)b.take((size_t)M * C * 4); q.h1t = b.take((size_t)M * C * es);
+      q.z = c.train_swin ? b.take((size_t)M * F * es) : nullptr;
+      q.a = b.take((size_t)M * F * es); q.fo = b.take((size_t)M * C * es);
+      q.mean2 = (float*)b.take((size_t)M * 4); q.rstd2 = (float*)b.take((size_t)M * 4);
+      q.h2 = (float*)b.take((size_t)M * C * 4); q.h2t = b.take((size_t)M * C * es);
+      q.bias = (float*)b.take((size_t)H * n * n * 4); q.table = (float*)b.take((size_t)ntab * H * 4);
+      q.hidden = (float*)b.take((size_t)ntab * 512 * 4);
+    }
+    sb.mg = sb.mo = nullptr; sb.mmean = sb.mrstd = nullptr; sb.xm = nullptr; sb.xmt = nullptr;
+    if (st < s.n_stages - 1) {
+      const long M2 = M / 4;
+      sb.mg = b.take((size_t)M2 * 4 * C * es); sb.mo = b.take((size_t)M2 * 2 * C * es);
+      sb.mmean = (float*)b.take((size_t)M2 * 4); sb.mrstd = (float*)b.take((size_t)M2 * 4);
+      sb.xm = (float*)b.take((size_t)M2 * 2 * C * 4); sb.xmt = b.take((size_t)M2 * 2 * C * es);
+    }
+  }
+  const long Ml = (long)B * Nimg;
+  e->sw_fmean = (float*)b.take((size_t)Ml * 4); e->sw_frstd = (float*)b.take((size_t)Ml * 4);
+  if (c.train_swin) {
+    const long F0 = (long)s.mlp_ratio;
+    e->sdh_a = (float*)b.take((size_t)maxMC * 4); e->sdh_b = (float*)b.take((size_t)maxMC * 4);
+    e->sdm = (float*)b.take((size_t)maxMC * 4);
+    e->sdy = b.take((size_t)maxMC * es); e->sdctx = b.take((size_t)maxMC * es);
+    e->sdqkv = b.take((size_t)maxMC * 3 * es); e->sda = b.take((size_t)maxMC * F0 * es);
+    int maxn = 0, maxH = 0;
+    for (int st = 0; st < s.n_stages; ++st) {
+      const int R = R0 >> st; const int w = R < s.window ? R : s.window;
+      if (w * w > maxn) maxn = w * w;
+      if (s.heads[st] > maxH) maxH = s.heads[st];
+    }
+    e->sdbias = (float*)b.take((size_t)maxH * maxn * maxn * 4);
+    e->sdtable = (float*)b.take((size_t)(4 * maxn) * maxH * 4 + (size_t)(4 * maxn) * 512 * 4);
+  }
+  return (b.off + 255) & ~(size_t)255;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------------
+struct Ctx {
+  klab_engine* e; hipStream_t s; int dt; size_t es;
+  void* ws() const { return (void*)s; }
+};
+
+klab_gemm_args G0(const Ctx& c, int M, int N, int K, const void* A, long lda, int ak, const void* B, long ldb, int bk, void* C,
+                  long ldc, int cdt) {
+  klab_gemm_args g;
+  memset(&g, 0, sizeof(g));
+  g.M = M; g.N = N; g.K = K; g.dtype = c.dt;
+  g.A = A; g.lda = lda; g.a_kmajor = ak; g.B = B; g.ldb = ldb; g.b_kmajor = bk;
+  g.C = C; g.ldc = ldc; g.c_dtype = cdt; g.alpha = 1.f;
+  return g;
+}
+inline void* woff(const Ctx& c, long off) { return (char*)c.e->warena + (size_t)off * c.es; }
+inline void* eoff(const Ctx& c, void* p, long elems) { return (char*)p + (size_t)elems * c.es; }
+
+// y = x @ W^T   (W [N,K] from the weight arena)
+int linear_fwd(const Ctx& c, const void* x, int M, int K, long woffv, int N, void* y, long ldy, int ydt, const float* bias = nullptr,
+               int act = 0) {
+  klab_gemm_args g = G0(c, M, N, K, x, K, 1, woff(c, woffv), K, 1, y, ldy, ydt);
+  g.bias = bias; g.act = act;
+  return klab_gemm(&g, c.ws());
+}
+// dX[M,K] = dY[M,N] @ W[N,K]
+int linear_dgrad(const Ctx& c, const void* dy, long lddy, int M, int N, long woffv, int K, void* dx, int dxdt) {
+  klab_gemm_args g = G0(c, M, K, N, dy, lddy, 1, woff(c, woffv), K, 0, dx, K, dxdt);
+  return klab_gemm(&g, c.ws());
+}
+// dW[N,K] = dY[M,N]^T @ X[M,K]  -> f32 grads
+int linear_wgrad(const Ctx& c, const void* dy, long lddy, const void* x, long ldx, int M, int N, int K, float* dw) {
+  klab_gemm_args g = G0(c, N, K, M, dy, lddy, 0, x, ldx, 0, dw, K, KLAB_F32);
+  return klab_gemm(&g, c.ws());
+}
+
+int t5_sublayer_out(const Ctx& c, const void* x, int M, int K, long woffv, int d, const float* resid, float* hout, float p, uint32_t tag) {
+  klab_gemm_args g = G0(c, M, d, K, x, K, 1, woff(c, woffv), K, 1, hout, d, KLAB_F32);
+  g.residual = resid; g.ldr = d; g.r_dtype = KLAB_F32;
+  g.drop_p = p; g.seed_dev = c.e->seed_dev; g.drop_tag = tag;
+  return klab_gemm(&g, c.ws());
+}
+
+// ------------------------------------------------------------------------------------------------
+// T5 stack forward (HF/t5:663-750); `h[0]` must already hold dropout(inputs_embeds)
+// ------------------------------------------------------------------------------------------------
+int t5_stack_forward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<ParamInfo>& P, const std::vector<const float*>& W,
+                     const std::vector<T5LayerIdx>& L, int final_ln, T5StackBufs& s, bool dec, int stack_id, float p, int B,
+                     const void* kv_all, int Lkv, long kv_ld, float* out_f32, int grp, int grp_stride, int off, float p_final) {
+  const int d = cfg.d_model, H = cfg.n_heads, dk = cfg.d_kv, inner = H * dk, ff = cfg.d_ff;
+  const int M = s.M, Lq = s.Lseq;
+  const int relb = L[0].relb;
+  RC(klab_relbias_fwd(W[relb], s.bucket, s.bias, H, Lq, Lq, c.ws()));
+  int j = 0;
+  for (size_t i = 0; i < L.size(); ++i) {
+    const T5LayerIdx& l = L[i];
+    T5LayerBufs& b = s.L[i];
+    // --- self attention (HF/t5:372-401) ---
+    RC(klab_rmsnorm_fwd(s.h[j], W[l.ln0], b.xn1, c.dt, nullptr, b.rstd1, M, d, cfg.ln_eps, 0, 0, 0, 0.f, nullptr, 0, c.ws()));
+    RC(linear_fwd(c, b.xn1, M, d, P[l.q].warena_off, 3 * inner, b.qkv, 3 * inner, c.dt));
+    {
+      klab_attn_args a;
+      memset(&a, 0, sizeof(a));
+      a.dtype = c.dt; a.q = b.qkv; a.ldq = 3 * inner; a.k = eoff(c, b.qkv, inner); a.ldk = 3 * inner;
+      a.v = eoff(c, b.qkv, 2 * inner); a.ldv = 3 * inner; a.bias = s.bias; a.causal = dec ? 1 : 0;
+      a.ctx = b.ctx; a.ldo = inner; a.lse = b.lse; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lq; a.dk = dk;
+      a.drop_p = p; a.seed_dev = c.e->seed_dev; a.drop_tag = tag_of(stack_id, (int)i, SITE_PROB);
+      RC(klab_t5_attn_fwd(&a, c.ws()));
+    }
+    RC(t5_sublayer_out(c, b.ctx, M, inner, P[l.o].warena_off, d, s.h[j], s.h[j + 1], p, tag_of(stack_id, (int)i, SITE_ATTN_OUT)));
+    ++j;
+    if (dec) {  // --- cross attention (HF/t5:404-432), K/V of all layers projected once ---
+      RC(klab_rmsnorm_fwd(s.h[j], W[l.ln1], b.xn2, c.dt, nullptr, b.rstd2, M, d, cfg.ln_eps, 0, 0, 0, 0.f, nullptr, 0, c.ws()));
+      RC(linear_fwd(c, b.xn2, M, d, P[l.cq].warena_off, inner, b.qc, inner, c.dt));
+      klab_attn_args a;
+      memset(&a, 0, sizeof(a));
+      a.dtype = c.dt; a.q = b.qc; a.ldq = inner;
+      a.k = eoff(c, (void*)kv_all, (long)i * 2 * inner); a.ldk = kv_ld;
+      a.v = eoff(c, (void*)kv_all, (long)i * 2 * inner + inner); a.ldv = kv_ld;
+      a.bias = nullptr; a.causal = 0; a.ctx = b.ctx2; a.ldo = inner; a.lse = b.lse2;
+      a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lkv; a.dk = dk;
+      a.drop_p = p; a.seed_dev = c.e->seed_dev; a.drop_tag = tag_of(stack_id, (int)i, SITE_XPROB);
+      RC(klab_t5_attn_fwd(&a, c.ws()));
+      RC(t5_sublayer_out(c, b.ctx2, M, inner, P[l.co].warena_off, d, s.h[j], s.h[j + 1], p, tag_of(stack_id, (int)i, SITE_XOUT)));
+      ++j;
+    }
+    // --- feed forward (HF/t5:83-94,137-141) ---
+    RC(klab_rmsnorm_fwd(s.h[j], W[l.ln2], b.xn3, c.dt, nullptr, b.rstd3, M, d, cfg.ln_eps, 0, 0, 0, 0.f, nullptr, 0, c.ws()));
+    {
+      klab_gemm_args g = G0(c, M, ff, d, b.xn3, d, 1, woff(c, P[l.wi].warena_off), d, 1, b.hmid, ff, c.dt);
+      g.act = KLAB_ACT_RELU; g.drop_p = p; g.seed_dev = c.e->seed_dev; g.drop_tag = tag_of(stack_id, (int)i, SITE_MID);
+      RC(klab_gemm(&g, c.ws()));
+    }
+    RC(t5_sublayer_out(c, b.hmid, M, ff, P[l.wo].warena_off, d, s.h[j], s.h[j + 1], p, tag_of(stack_id, (int)i, SITE_FFN_OUT)));
+    ++j;
+  }
+  // final norm + dropout (HF/t5:744-745)
+  RC(klab_rmsnorm_fwd(s.h[j], W[final_ln], out_f32 ? nullptr : s.out_t, c.dt, out_f32, s.rstd_f, M, d, cfg.ln_eps, grp, grp_stride, off,
+                      p_final, c.e->seed_dev, out_f32 ? tag_of(STACK_ENC, 0, SITE_IN) : tag_of(stack_id, 0, SITE_FINAL), c.ws()));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// T5 stack backward.  In: dxn = d loss / d (final-norm output) in f32 [M,d].  Out: dh_cur = d loss / d h[0].
+// ------------------------------------------------------------------------------------------------
+int t5_stack_backward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<ParamInfo>& P, const std::vector<const float*>& W,
+                      float* Gflat, const std::vector<T5LayerIdx>& L, int final_ln, T5StackBufs& s, bool dec, int stack_id, float p,
+                      int B, const void* kv_all, void* dkv_all, int Lkv, long kv_ld, float** dh_out) {
+  klab_engine* e = c.e;
+  const int d = cfg.d_model, H = cfg.n_heads, dk = cfg.d_kv, inner = H * dk, ff = cfg.d_ff;
+  const int M = s.M, Lq = s.Lseq;
+  const int nsub = dec ? 3 : 2;
+  int j = nsub * (int)L.size();
+  float* dh_cur = e->dh_a;
+  float* dh_oth = e->dh_b;
+  auto G = [&](int pi) { return Gflat + P[pi].grad_off; };
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  RC(hipMemsetAsync(s.dbias, 0, (size_t)H * Lq * Lq * 4, c.s));
+  // final norm: y = drop(norm(h[j])); previous sub-layer output dropout = FFN_OUT of the last layer
+  RC(klab_rmsnorm_bwd(e->dxn, s.h[j], W[final_ln], s.rstd_f, nullptr, dh_cur, e->dy_t, c.dt, G(final_ln), M, d, 0, 0, 0, p,
+                      tag_of(stack_id, 0, SITE_FINAL), p, tag_of(stack_id, (int)L.size() - 1, SITE_FFN_OUT), e->seed_dev, c.ws()));
+  for (int i = (int)L.size() - 1; i >= 0; --i) {
+    const T5LayerIdx& l = L[i];
+    T5LayerBufs& b = s.L[i];
+    // ---------------- FFN ----------------
+    --j;
+    RC(linear_wgrad(c, e->dy_t, d, b.hmid, ff, M, d, ff, G(l.wo)));
+    {
+      klab_gemm_args g = G0(c, M, ff, d, e->dy_t, d, 1, woff(c, P[l.wo].warena_off), ff, 0, e->dhmid, ff, c.dt);
+      g.aux = b.hmid; g.ldaux = ff; g.aux_mode = KLAB_AUX_NONZERO; g.aux_scale = inv_keep;
+      RC(klab_gemm(&g, c.ws()));
+    }
+    RC(linear_wgrad(c, e->dhmid, ff, b.xn3, d, M, ff, d, G(l.wi)));
+    RC(linear_dgrad(c, e->dhmid, ff, M, ff, P[l.wi].warena_off, d, e->dxn, KLAB_F32));
+    {
+      const uint32_t tprev = dec ? tag_of(stack_id, i, SITE_XOUT) : tag_of(stack_id, i, SITE_ATTN_OUT);
+      RC(klab_rmsnorm_bwd(e->dxn, s.h[j], W[l.ln2], b.rstd3, dh_cur, dh_oth, e->dy_t, c.dt, G(l.ln2), M, d, 0, 0, 0, 0.f, 0, p, tprev,
+                          e->seed_dev, c.ws()));
+      float* t = dh_cur; dh_cur = dh_oth; dh_oth = t;
+    }
+    if (dec) {  // ---------------- cross attention ----------------
+      --j;
+      RC(linear_wgrad(c, e->dy_t, d, b.ctx2, inner, M, d, inner, G(l.co)));
+      RC(linear_dgrad(c, e->dy_t, d, M, d, P[l.co].warena_off, inner, e->dctx, c.dt));
+      klab_attn_args a;
+      memset(&a, 0, sizeof(a));
+      a.dtype = c.dt; a.q = b.qc; a.ldq = inner;
+      a.k = eoff(c, (void*)kv_all, (long)i * 2 * inner); a.ldk = kv_ld;
+      a.v = eoff(c, (void*)kv_all, (long)i * 2 * inner + inner); a.ldv = kv_ld;
+      a.ctx = b.ctx2; a.ldo = inner; a.lse = b.lse2; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lkv; a.dk = dk;
+      a.drop_p = p; a.seed_dev = e->seed_dev; a.drop_tag = tag_of(stack_id, i, SITE_XPROB);
+      a.dctx = e->dctx; a.lddo = inner; a.dq = e->dqc; a.lddq = inner;
+      a.dk_out = eoff(c, dkv_all, (long)i * 2 * inner); a.lddk = kv_ld;
+      a.dv = eoff(c, dkv_all, (long)i * 2 * inner + inner); a.lddv = kv_ld;
+      RC(klab_t5_attn_bwd(&a, c.ws()));
+      RC(linear_wgrad(c, e->dqc, inner, b.xn2, d, M, inner, d, G(l.cq)));
+      RC(linear_dgrad(c, e->dqc, inner, M, inner, P[l.cq].warena_off, d, e->dxn, KLAB_F32));
+      RC(klab_rmsnorm_bwd(e->dxn, s.h[j], W[l.ln1], b.rstd2, dh_cur, dh_oth, e->dy_t, c.dt, G(l.ln1), M, d, 0, 0, 0, 0.f, 0, p,
+                          tag_of(stack_id, i, SITE_ATTN_OUT), e->seed_dev, c.ws()));
+      float* t = dh_cur; dh_cur = dh_oth; dh_oth = t;
+    }
+    // ---------------- self attention ----------------
+    --j;
+    RC(linear_wgrad(c, e->dy_t, d, b.ctx, inner, M, d, inner, G(l.o)));
+    RC(linear_dgrad(c, e->dy_t, d, M, d, P[l.o].warena_off, inner, e->dctx, c.dt));
+    {
+      klab_attn_args a;
+      memset(&a, 0, sizeof(a));
+      a.dtype = c.dt; a.q = b.qkv; a.ldq = 3 * inner; a.k = eoff(c, b.qkv, inner); a.ldk = 3 * inner;
+      a.v = eoff(c, b.qkv, 2 * inner); a.ldv = 3 * inner; a.bias = s.bias; a.causal = dec ? 1 : 0;
+      a.ctx = b.ctx; a.ldo = inner; a.lse = b.lse; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lq; a.dk = dk;
+      a.drop_p = p; a.seed_dev = e->seed_dev; a.drop_tag = tag_of(stack_id, i, SITE_PROB);
+      a.dctx = e->dctx; a.lddo = inner; a.dq = e->dqkv; a.lddq = 3 * inner;
+      a.dk_out = eoff(c, e->dqkv, inner); a.lddk = 3 * inner; a.dv = eoff(c, e->dqkv, 2 * inner); a.lddv = 3 * inner;
+      a.dbias = s.dbias;
+      RC(klab_t5_attn_bwd(&a, c.ws()));
+    }
+    RC(linear_wgrad(c, e->dqkv, 3 * inner, b.xn1, d, M, 3 * inner, d, G(l.q)));  // q|k|v grads are adjacent
+    RC(linear_dgrad(c, e->dqkv, 3 * inner, M, 3 * inner, P[l.q].warena_off, d, e->dxn, KLAB_F32));
+    {
+      const bool first = (i == 0);
+      RC(klab_rmsnorm_bwd(e->dxn, s.h[j], W[l.ln0], b.rstd1, dh_cur, dh_oth, first ? nullptr : e->dy_t, c.dt, G(l.ln0), M, d, 0, 0, 0, 0.f, 0,
+                          first ? 0.f : p, first ? 0u : tag_of(stack_id, i - 1, SITE_FFN_OUT), e->seed_dev, c.ws()));
+      float* t = dh_cur; dh_cur = dh_oth; dh_oth = t;
+    }
+  }
+  RC(klab_relbias_bwd(s.dbias, s.bucket, G(L[0].relb), H, Lq, Lq, cfg.rel_buckets, c.ws()));
+  *dh_out = dh_cur;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Swin-V2 forward (HF/swinv2:917-958, eval mode always: SURVEY §0.4)
+// ------------------------------------------------------------------------------------------------
+int swin_forward(const Ctx& c, const float* pixels, float p_in) {
+  klab_engine* e = c.e;
+  const klab_swin_cfg& s = e->cfg.swin;
+  const auto& P = e->P[0];
+  const auto& W = e->W[0];
+  const int B = e->B, R0 = s.image_size / s.patch, K0 = s.in_ch * s.patch * s.patch, C0 = s.embed_dim;
+  const long M0 = (long)B * R0 * R0;
+  RC(klab_im2col_patch(pixels, e->cols, c.dt, B, s.in_ch, s.image_size, s.patch, c.ws()));
+  RC(linear_fwd(c, e->cols, (int)M0, K0, P[e->si.pew].warena_off, C0, e->pe_out, C0, c.dt, W[e->si.peb]));
+  RC(klab_layernorm_fwd(e->pe_out, c.dt, W[e->si.penw], W[e->si.penb], nullptr, e->x0, e->x0t, c.dt, e->pe_mean, e->pe_rstd, (int)M0, C0,
+                        s.ln_eps, 0, 0, 0, 0.f, nullptr, 0, c.ws()));
+  float* x = e->x0;
+  void* xt = e->x0t;
+  long bias_off = 0;
+  for (int st = 0; st < s.n_stages; ++st) {
+    SwinStageBufs& sb = e->sw[st];
+    for (size_t k = 0; k < sb.blk.size(); ++k) {
+      SwinBlockBufs& q = sb.blk[k];
+      const SwinBlockIdx& ix = e->si.st[st].blk[k];
+      const int C = q.C, M = (int)q.M, F = s.mlp_ratio * C, n = q.w * q.w;
+      q.x_in = x; q.xt_in = xt;
+      RC(klab_swin_cpb_bias(e->swin_coords[st], e->swin_index[st], W[ix.c0w], W[ix.c0b], W[ix.c2w], q.table, q.hidden, q.bias,
+                            e->swin_ntab[st], n, q.H, 512, c.ws()));
+      const float* qkvb = ix.qb >= 0 ? e->farena + bias_off : nullptr;
+      bias_off += 3 * C;
+      RC(linear_fwd(c, xt, M, C, P[ix.qw].warena_off, 3 * C, q.qkv, 3 * C, c.dt, qkvb));
+      klab_swin_attn_args a;
+      memset(&a, 0, sizeof(a));
+      a.dtype = c.dt; a.qkv = q.qkv; a.ctx = q.ctx; a.bias = q.bias; a.logit_scale = W[ix.ls]; a.lse = q.lse;
+      a.B = B; a.R = q.R; a.w = q.w; a.shift = q.shift; a.H = q.H; a.C = C;
+      RC(klab_swin_attn_fwd(&a, c.ws()));
+      RC(linear_fwd(c, q.ctx, M, C, P[ix.pw].warena_off, C, q.po, C, c.dt, W[ix.pb]));
+      RC(klab_layernorm_fwd(q.po, c.dt, W[ix.ln1w], W[ix.ln1b], x, q.h1, q.h1t, c.dt, q.mean1, q.rstd1, M, C, s.ln_eps, 0, 0, 0, 0.f,
+                            nullptr, 0, c.ws()));
+      if (e->cfg.train_swin) {  // keep the pre-activation for gelu'
+        RC(linear_fwd(c, q.h1t, M, C, P[ix.f1w].warena_off, F, q.z, F, c.dt, W[ix.f1b]));
+        RC(klab_gelu_fwd(q.z, q.a, c.dt, (long)M * F, c.ws()));
+      } else {
+        RC(linear_fwd(c, q.h1t, M, C, P[ix.f1w].warena_off, F, q.a, F, c.dt, W[ix.f1b], KLAB_ACT_GELU));
+      }
+      RC(linear_fwd(c, q.a, M, F, P[ix.f2w].warena_off, C, q.fo, C, c.dt, W[ix.f2b]));
+      RC(klab_layernorm_fwd(q.fo, c.dt, W[ix.ln2w], W[ix.ln2b], q.h1, q.h2, q.h2t, c.dt, q.mean2, q.rstd2, M, C, s.ln_eps, 0, 0, 0, 0.f,
+                            nullptr, 0, c.ws()));
+      x = q.h2; xt = q.h2t;
+    }
+    if (st < s.n_stages - 1) {
+      const int R = R0 >> st, C = C0 << st;
+      const long M2 = (long)B * (R / 2) * (R / 2);
+      RC(klab_merge_gather(x, sb.mg, c.dt, B, R, C, c.ws()));
+      RC(linear_fwd(c, sb.mg, (int)M2, 4 * C, P[e->si.st[st].redw].warena_off, 2 * C, sb.mo, 2 * C, c.dt));
+      RC(klab_layernorm_fwd(sb.mo, c.dt, W[e->si.st[st].mnw], W[e->si.st[st].mnb], nullptr, sb.xm, sb.xmt, c.dt, sb.mmean, sb.mrstd, (int)M2,
+                            2 * C, s.ln_eps, 0, 0, 0, 0.f, nullptr, 0, c.ws()));
+      x = sb.xm; xt = sb.xmt;
+    }
+  }
+  // final LayerNorm (HF/swinv2:953) written straight into rows [0, N_img) of the T5 encoder input,
+  // with the encoder's input dropout (HF/t5:725) applied on the way: ref/models/model.py:23 for free.
+  const int Cl = C0 << (s.n_stages - 1);
+  RC(klab_layernorm_fwd(x, KLAB_F32, W[e->si.lnw], W[e->si.lnb], nullptr, e->enc.h[0], nullptr, c.dt, e->sw_fmean, e->sw_frstd,
+                        B * e->Nimg, Cl, s.ln_eps, e->Nimg, e->Le, 0, p_in, e->seed_dev, tag_of(STACK_ENC, 0, SITE_IN), c.ws()));
+  return 0;
+}
+
+int swin_backward(const Ctx& c, const float* dh0, float p_in);
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" klab_engine* klab_engine_create(const klab_model_cfg* cfg) {
+  if (!cfg) return nullptr;
+  if (cfg->dtype != KLAB_F32 && cfg->dtype != KLAB_BF16) return nullptr;
+  const klab_swin_cfg& s = cfg->swin;
+  if (s.n_stages < 1 || s.n_stages > 8 || s.patch <= 0 || s.image_size % s.patch) return nullptr;
+  const long Cl = (long)s.embed_dim << (s.n_stages - 1);
+  // no projection between the towers: ref/models/model.py:23 concatenates on the sequence axis
+  if (Cl != cfg->main.d_model || cfg->lang.d_model != cfg->main.d_model) return nullptr;
+  klab_engine* e = new klab_engine();
+  e->cfg = *cfg;
+  build_swin_params(cfg->swin, e->P[0], e->si);
+  build_t5_params(cfg->lang, true, e->P[1], e->li);
+  build_t5_params(cfg->main, false, e->P[2], e->mi);
+  plan_arenas(e);
+  plan_grads(e);
+  return e;
+}
+
+extern "C" void klab_engine_destroy(klab_engine* e) { delete e; }
+
+extern "C" int klab_engine_num_params(const klab_engine* e, int model) {
+  if (!e || model < 0 || model > 2) return -1;
+  return (int)e->P[model].size();
+}
+
+extern "C" int klab_engine_param_info(const klab_engine* e, int model, int i, char* name, int name_cap, long* shape4, int* ndim,
+                                      long* grad_off) {
+  if (!e || model < 0 || model > 2 || i < 0 || i >= (int)e->P[model].size()) return KLAB_ERR_BADARG;
+  const ParamInfo& p = e->P[model][i];
+  if (name && name_cap > 0) { strncpy(name, p.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+  if (ndim) *ndim = (int)p.shape.size();
+  if (shape4) for (size_t k = 0; k < 4; ++k) shape4[k] = k < p.shape.size() ? p.shape[k] : 1;
+  if (grad_off) *grad_off = p.grad_off;
+  return 0;
+}
+
+extern "C" long klab_engine_grad_elems(const klab_engine* e, int model) { return (e && model >= 0 && model <= 2) ? e->grad_elems[model] : -1; }
+
+extern "C" int klab_engine_segment(const klab_engine* e, int seg, int* model, long* off, long* len) {
+  if (!e || seg < 0 || seg > 2) return KLAB_ERR_BADARG;
+  if (model) *model = seg == 2 ? 0 : 2;
+  if (off) *off = e->seg_off[seg];
+  if (len) *len = e->seg_len[seg];
+  return 0;
+}
+
+extern "C" size_t klab_engine_workspace_bytes(klab_engine* e, int B, int Ls, int Lt) {
+  if (!e || B <= 0 || Ls <= 0 || Lt <= 0) return 0;
+  klab_engine tmp = *e;  // plan on a scratch copy: bound state of `e` is untouched
+  return plan_workspace(&tmp, nullptr, B, Ls, Lt);
+}
+
+extern "C" int klab_engine_bind(klab_engine* e, int B, int Ls, int Lt, void* workspace, size_t ws_bytes, const void* const* swin_params,
+                                const void* const* lang_params, const void* const* main_params, float* main_grads, float* swin_grads,
+                                const int* lang_bucket, const int* enc_bucket, const int* dec_bucket, const void* const* swin_coords,
+                                const void* const* swin_index, void* stream) {
+  if (!e || !workspace || !swin_params || !lang_params || !main_params || !main_grads) return KLAB_ERR_BADARG;
+  if (e->cfg.train_swin && !swin_grads) return KLAB_ERR_BADARG;
+  const size_t need = plan_workspace(e, workspace, B, Ls, Lt);
+  if (need > ws_bytes) return KLAB_ERR_BADARG;
+  const void* const* src[3] = {swin_params, lang_params, main_params};
+  for (int m = 0; m < 3; ++m) {
+    e->W[m].resize(e->P[m].size());
+    for (size_t i = 0; i < e->P[m].size(); ++i) {
+      e->W[m][i] = (const float*)src[m][i];
+      if (!e->W[m][i]) return KLAB_ERR_BADARG;
+    }
+  }
+  e->G[0] = swin_grads; e->G[2] = main_grads;
+  e->lang_bucket = lang_bucket; e->enc_bucket = enc_bucket; e->dec_bucket = dec_bucket;
+  e->lang.bucket = lang_bucket; e->enc.bucket = enc_bucket; e->dec.bucket = dec_bucket;
+  const klab_swin_cfg& s = e->cfg.swin;
+  e->swin_coords.resize(s.n_stages); e->swin_index.resize(s.n_stages); e->swin_ntab.resize(s.n_stages);
+  const int R0 = s.image_size / s.patch;
+  for (int st = 0; st < s.n_stages; ++st) {
+    e->swin_coords[st] = (const float*)swin_coords[st];
+    e->swin_index[st] = (const int*)swin_index[st];
+    const int R = R0 >> st, w = R < s.window ? R : s.window;
+    if (w <= 0 || R % w) return KLAB_ERR_UNSUPPORTED;
+    e->swin_ntab[st] = (2 * w - 1) * (2 * w - 1);
+  }
+  // cast descriptors: {src, dst_off, n4_prefix}
+  hipStream_t hs = (hipStream_t)stream;
+  {
+    std::vector<long> d;
+    long pre = 0; int n = 0;
+    for (int m = 0; m < 3; ++m)
+      for (size_t i = 0; i < e->P[m].size(); ++i) {
+        const ParamInfo& p = e->P[m][i];
+        if (p.warena_off < 0) continue;
+        if (p.numel % 4) return KLAB_ERR_UNSUPPORTED;
+        d.push_back((long)e->W[m][i]); d.push_back(p.warena_off); d.push_back(pre);
+        pre += p.numel / 4; ++n;
+      }
+    e->n_cast = n; e->cast_total4 = pre;
+    hipError_t er = hipMemcpyAsync(e->cast_desc, d.data(), d.size() * sizeof(long), hipMemcpyHostToDevice, hs);
+    if (er != hipSuccess) return (int)er;
+    er = hipStreamSynchronize(hs);  // bind time only (d goes out of scope)
+    if (er != hipSuccess) return (int)er;
+  }
+  {
+    std::vector<long> d;
+    long pre = 0; int n = 0;
+    for (size_t i = 0; i < e->P[0].size(); ++i) {
+      const ParamInfo& p = e->P[0][i];
+      if (p.farena_off < 0) continue;
+      if (p.numel % 4) return KLAB_ERR_UNSUPPORTED;
+      d.push_back((long)e->W[0][i]); d.push_back(p.farena_off); d.push_back(pre);
+      pre += p.numel / 4; ++n;
+    }
+    e->n_fcast = n; e->fcast_total4 = pre;
+    RC((int)hipMemsetAsync(e->farena, 0, (size_t)e->farena_elems * 4, hs));
+    if (n) {
+      hipError_t er = hipMemcpyAsync(e->fcast_desc, d.data(), d.size() * sizeof(long), hipMemcpyHostToDevice, hs);
+      if (er != hipSuccess) return (int)er;
+      er = hipStreamSynchronize(hs);
+      if (er != hipSuccess) return (int)er;
+    }
+  }
+  RC((int)hipMemsetAsync(e->seed_dev, 0, 256, hs));
+  e->bound = true;
+  return 0;
+}
+
+extern "C" int klab_engine_forward(klab_engine* e, const float* pixels, const long long* src_ids, const long long* tgt_ids, int training,
+                                   uint32_t seed, int want_grad, void* stream) {
+  if (!e || !e->bound || !pixels || !src_ids || !tgt_ids) return KLAB_ERR_BADARG;
+  Ctx c{e, (hipStream_t)stream, e->cfg.dtype, e->es};
+  const klab_model_cfg& cfg = e->cfg;
+  const float p = training ? cfg.main.dropout : 0.f;
+  e->p_train = p;
+  e->last_tgt = tgt_ids;
+  RC((int)hipMemcpyAsync(e->seed_dev, &seed, 4, hipMemcpyHostToDevice, c.s));  // pageable 4-byte copy: value captured at call time
+  // 1. weights: fp32 masters -> compute-dtype arena (+ fused f32 bias vectors)
+  RC(klab_cast_pack(e->cast_desc, e->n_cast, e->cast_total4, e->warena, c.dt, c.ws()));
+  if (e->n_fcast) RC(klab_cast_pack(e->fcast_desc, e->n_fcast, e->fcast_total4, e->farena, KLAB_F32, c.ws()));
+  const int B = e->B, d = cfg.main.d_model;
+  // 2. frozen language encoder, eval mode (ref/models/model.py:20-21) -> rows [N_img, Le) of enc.h[0]
+  RC(klab_embed_fwd(src_ids, 0, e->Ls, 0, 0, e->W[1][e->li.shared], cfg.lang.vocab, e->lang.h[0], B * e->Ls, d, 0.f, nullptr, 0, e->err_dev,
+                    c.ws()));
+  RC(t5_stack_forward(c, cfg.lang, e->P[1], e->W[1], e->li.enc, e->li.enc_final, e->lang, false, STACK_LANG, 0.f, B, nullptr, 0, 0,
+                      e->enc.h[0], e->Ls, e->Le, e->Nimg, p));
+  // 3. Swin-V2 (ref/models/model.py:22) -> rows [0, N_img)
+  RC(swin_forward(c, pixels, p));
+  // 4. T5 encoder (HF/t5:1009-1016)
+  RC(t5_stack_forward(c, cfg.main, e->P[2], e->W[2], e->mi.enc, e->mi.enc_final, e->enc, false, STACK_ENC, p, B, nullptr, 0, 0, nullptr, 0, 0, 0,
+                      p));
+  // 5. decoder: shift_right + embedding (HF/t5:1026-1028), cross K/V of all layers in one GEMM, stack, LM head + CE
+  const int inner = cfg.main.n_heads * cfg.main.d_kv, nld = cfg.main.n_dec_layers;
+  RC(klab_embed_fwd(tgt_ids, 1, e->Lt, cfg.main.start_id, cfg.main.pad_id, e->W[2][e->mi.shared], cfg.main.vocab, e->dec.h[0], B * e->Lt, d, p,
+                    e->seed_dev, tag_of(STACK_DEC, 0, SITE_IN), e->err_dev, c.ws()));
+  RC(linear_fwd(c, e->enc.out_t, B * e->Le, d, e->kvall_w_off, nld * 2 * inner, e->kv_all, (long)nld * 2 * inner, c.dt));
+  RC(t5_stack_forward(c, cfg.main, e->P[2], e->W[2], e->mi.dec, e->mi.dec_final, e->dec, true, STACK_DEC, p, B, e->kv_all, e->Le,
+                      (long)nld * 2 * inner, nullptr, 0, 0, 0, p));
+  {
+    const int Md = B * e->Lt, V = cfg.main.vocab;
+    klab_gemm_args g = G0(c, Md, V, d, e->dec.out_t, d, 1, woff(c, e->P[2][e->mi.shared].warena_off), d, 1, e->logits, V, c.dt);
+    g.alpha = cfg.main.scale_decoder_outputs ? 1.f / sqrtf((float)d) : 1.f;  // HF/t5:1044-1045
+    RC(klab_gemm(&g, c.ws()));
+    RC(klab_ce_fwd(e->logits, V, c.dt, tgt_ids, Md, V, e->inv_n, e->loss_row, e->loss, want_grad, c.ws()));
+  }
+  return 0;
+}
+
+extern "C" const float* klab_engine_loss_ptr(const klab_engine* e) { return e ? e->loss : nullptr; }
+extern "C" const int* klab_engine_err_ptr(const klab_engine* e) { return e ? e->err_dev : nullptr; }
+
+extern "C" const void* klab_engine_buffer(const klab_engine* e, const char* name, long* rows, long* cols, int* dtype) {
+  if (!e || !e->bound || !name) return nullptr;
+  const int d = e->cfg.main.d_model;
+  auto set = [&](long r, long c2, int dt) { if (rows) *rows = r; if (cols) *cols = c2; if (dtype) *dtype = dt; };
+  if (!strcmp(name, "encoder_input")) { set((long)e->B * e->Le, d, KLAB_F32); return e->enc.h[0]; }
+  if (!strcmp(name, "encoder_out")) { set((long)e->B * e->Le, d, e->cfg.dtype); return e->enc.out_t; }
+  if (!strcmp(name, "decoder_out")) { set((long)e->B * e->Lt, d, e->cfg.dtype); return e->dec.out_t; }
+  if (!strcmp(name, "logits")) { set((long)e->B * e->Lt, e->cfg.main.vocab, e->cfg.dtype); return e->logits; }
+  return nullptr;
+}
+
+// segment 0: LM head + decoder + shared embedding; 1: encoder; 2: Swin
+extern "C" int klab_engine_backward(klab_engine* e, int segment, const float* dloss_dev, void* stream) {
+  if (!e || !e->bound) return KLAB_ERR_BADARG;
+  Ctx c{e, (hipStream_t)stream, e->cfg.dtype, e->es};
+  const klab_model_cfg& cfg = e->cfg;
+  const int B = e->B, d = cfg.main.d_model, inner = cfg.main.n_heads * cfg.main.d_kv, nld = cfg.main.n_dec_layers;
+  const float p = e->p_train;
+  float* Gm = e->G[2];
+  if (segment == 0) {
+    RC((int)hipMemsetAsync(Gm + e->seg_zero_off[0], 0, (size_t)e->seg_zero_len[0] * 4, c.s));
+    const int Md = B * e->Lt, V = cfg.main.vocab;
+    const float alpha = cfg.main.scale_decoder_outputs ? 1.f / sqrtf((float)d) : 1.f;
+    {  // d(dec_out) [Md,d] = dlogits [Md,V] @ shared [V,d]
+      klab_gemm_args g = G0(c, Md, d, V, e->logits, V, 1, woff(c, e->P[2][e->mi.shared].warena_off), d, 0, e->dxn, d, KLAB_F32);
+      g.alpha = alpha; g.alpha_dev = dloss_dev;
+      RC(klab_gemm(&g, c.ws()));
+    }
+    {  // d shared [V,d] = dlogits^T @ dec_out  (first of the tied weight's three contributors)
+      klab_gemm_args g = G0(c, V, d, Md, e->logits, V, 0, e->dec.out_t, d, 0, Gm + e->P[2][e->mi.shared].grad_off, d, KLAB_F32);
+      g.alpha = alpha; g.alpha_dev = dloss_dev;
+      RC(klab_gemm(&g, c.ws()));
+    }
+    float* dh0 = nullptr;
+    RC(t5_stack_backward(c, cfg.main, e->P[2], e->W[2], Gm, e->mi.dec, e->mi.dec_final, e->dec, true, STACK_DEC, p, B, e->kv_all, e->dkv_all,
+                         e->Le, (long)nld * 2 * inner, &dh0));
+    // decoder input embedding: scatter-add into the tied table (second contributor)
+    RC(klab_embed_bwd(e->last_tgt, 1, e->Lt, cfg.main.start_id, cfg.main.pad_id, dh0, Gm + e->P[2][e->mi.shared].grad_off, V, Md, d, p,
+                      e->seed_dev, tag_of(STACK_DEC, 0, SITE_IN), c.ws()));
+    // cross-attention K/V projections of all layers at once: weights + d(encoder output)
+    const int Me = B * e->Le, Nkv = nld * 2 * inner;
+    RC(linear_wgrad(c, e->dkv_all, Nkv, e->enc.out_t, d, Me, Nkv, d, Gm + e->kvall_g_off));
+    RC(linear_dgrad(c, e->dkv_all, Nkv, Me, Nkv, e->kvall_w_off, d, e->denc, KLAB_F32));
+    return 0;
+  }
+  if (segment == 1) {
+    RC((int)hipMemsetAsync(Gm + e->seg_zero_off[1], 0, (size_t)e->seg_zero_len[1] * 4, c.s));
+    // the stack consumes dxn as d(final-norm output)
+    const int Me = B * e->Le;
+    RC((int)hipMemcpyAsync(e->dxn, e->denc, (size_t)Me * d * 4, hipMemcpyDeviceToDevice, c.s));
+    float* dh0 = nullptr;
+    RC(t5_stack_backward(c, cfg.main, e->P[2], e->W[2], Gm, e->mi.enc, e->mi.enc_final, e->enc, false, STACK_ENC, p, B, nullptr, nullptr, 0, 0,
+                         &dh0));
+    if (cfg.train_swin) RC((int)hipMemcpyAsync(e->denc, dh0, (size_t)Me * d * 4, hipMemcpyDeviceToDevice, c.s));
+    return 0;
+  }
+  if (segment == 2) {
+    if (!cfg.train_swin) return 0;
+    return swin_backward(c, e->denc, p);
+  }
+  return KLAB_ERR_BADARG;
+}
+
+namespace {
+
+// Swin-V2 backward (only with --image_model_train; Swin itself is always in eval mode).  dh0 is
+// d loss / d (encoder input) [B*Le, d] in f32; rows [0, N_img) of each image belong to Swin.
+int swin_backward(const Ctx& c, const float* dh0, float p_in) {
+  klab_engine* e = c.e;
+  const klab_swin_cfg& s = e->cfg.swin;
+  const auto& P = e->P[0];
+  const auto& W = e->W[0];
+  float* Gs = e->G[0];
+  auto G = [&](int pi) { return Gs + P[pi].grad_off; };
+  const int B = e->B, R0 = s.image_size / s.patch, C0 = s.embed_dim;
+  RC((int)hipMemsetAsync(Gs + e->seg_zero_off[2], 0, (size_t)e->seg_zero_len[2] * 4, c.s));
+  // final LN backward: input x = last hidden (f32), dout in the remapped encoder-input rows, with the input dropout
+  const int last = s.n_stages - 1;
+  const int Cl = C0 << last;
+  const SwinStageBufs& lsb = e->sw[last];
+  const float* xlast = lsb.blk.empty() ? (last > 0 ? e->sw[last - 1].xm : e->x0) : lsb.blk.back().h2;
+  float* dh = e->sdh_a;   // d loss / d hidden stream (f32)
+  float* dh2 = e->sdh_b;
+  RC(klab_layernorm_bwd(dh0, xlast, KLAB_F32, W[e->si.lnw], e->sw_fmean, e->sw_frstd, dh, G(e->si.lnw), G(e->si.lnb), B * e->Nimg, Cl,
+                        e->Nimg, e->Le, 0, p_in, e->seed_dev, tag_of(STACK_ENC, 0, SITE_IN), c.ws()));
+  long bias_off_total = 0;
+  for (int st = 0; st < s.n_stages; ++st) bias_off_total += 3L * (C0 << st) * s.depths[st];
+  long bias_off = bias_off_total;
+  (void)bias_off;
+  for (int st = last; st >= 0; --st) {
+    SwinStageBufs& sb = e->sw[st];
+    const int R = R0 >> st, C = C0 << st;
+    if (st < last) {
+      // patch merging backward: LN -> reduction -> gather
+      const long M2 = (long)B * (R / 2) * (R / 2);
+      RC(klab_layernorm_bwd(dh, sb.mo, c.dt, W[e->si.st[st].mnw], sb.mmean, sb.mrstd, e->sdy, G(e->si.st[st].mnw), G(e->si.st[st].mnb), (int)M2,
+                            2 * C, 0, 0, 0, 0.f, nullptr, 0, c.ws()));
+      RC(linear_wgrad(c, e->sdy, 2 * C, sb.mg, 4 * C, (int)M2, 2 * C, 4 * C, G(e->si.st[st].redw)));
+      RC(linear_dgrad(c, e->sdy, 2 * C, (int)M2, 2 * C, P[e->si.st[st].redw].warena_off, 4 * C, e->sdm, KLAB_F32));
+      RC(klab_merge_scatter(e->sdm, dh2, B, R, C, c.ws()));
+      float* t = dh; dh = dh2; dh2 = t;
+    }
+    for (int k = (int)sb.blk.size() - 1; k >= 0; --k) {
+      SwinBlockBufs& q = sb.blk[k];
+      const SwinBlockIdx& ix = e->si.st[st].blk[k];
+      const int M = (int)q.M, F = s.mlp_ratio * C, n = q.w * q.w;
+      // h2 = h1 + LN2(fo):  d fo = LN2'(dh);  dh flows through the shortcut unchanged
+      RC(klab_layernorm_bwd(dh, q.fo, c.dt, W[ix.ln2w], q.mean2, q.rstd2, e->sdy, G(ix.ln2w), G(ix.ln2b), M, C, 0, 0, 0, 0.f, nullptr, 0, c.ws()));
+      RC(klab_colsum(e->sdy, C, c.dt, M, C, G(ix.f2b), c.ws()));
+      RC(linear_wgrad(c, e->sdy, C, q.a, F, M, C, F, G(ix.f2w)));
+      {  // d z = (d fo @ W2) * gelu'(z)
+        klab_gemm_args g = G0(c, M, F, C, e->sdy, C, 1, woff(c, P[ix.f2w].warena_off), F, 0, e->sda, F, c.dt);
+        g.aux = q.z; g.ldaux = F; g.aux_mode = KLAB_AUX_DGELU;
+        RC(klab_gemm(&g, c.ws()));
+      }
+      RC(klab_colsum(e->sda, F, c.dt, M, F, G(ix.f1b), c.ws()));
+      RC(linear_wgrad(c, e->sda, F, q.h1t, C, M, F, C, G(ix.f1w)));
+      {  // dh1 = dh + d z @ W1   (accumulate into the stream gradient)
+        klab_gemm_args g = G0(c, M, C, F, e->sda, F, 1, woff(c, P[ix.f1w].warena_off), C, 0, dh, C, KLAB_F32);
+        g.accumulate = 1;
+        RC(klab_gemm(&g, c.ws()));
+      }
+      // h1 = x + LN1(po)
+      RC(klab_layernorm_bwd(dh, q.po, c.dt, W[ix.ln1w], q.mean1, q.rstd1, e->sdy, G(ix.ln1w), G(ix.ln1b), M, C, 0, 0, 0, 0.f, nullptr, 0, c.ws()));
+      RC(klab_colsum(e->sdy, C, c.dt, M, C, G(ix.pb), c.ws()));
+      RC(linear_wgrad(c, e->sdy, C, q.ctx, C, M, C, C, G(ix.pw)));
+      RC(linear_dgrad(c, e->sdy, C, M, C, P[ix.pw].warena_off, C, e->sdctx, c.dt));
+      RC((int)hipMemsetAsync(e->sdbias, 0, (size_t)q.H * n * n * 4, c.s));
+      klab_swin_attn_args a;
+      memset(&a, 0, sizeof(a));
+      a.dtype = c.dt; a.qkv = q.qkv; a.ctx = q.ctx; a.bias = q.bias; a.logit_scale = W[ix.ls]; a.lse = q.lse;
+      a.B = B; a.R = q.R; a.w = q.w; a.shift = q.shift; a.H = q.H; a.C = C;
+      a.dctx = e->sdctx; a.dqkv = e->sdqkv; a.dbias = e->sdbias; a.dlogit_scale = G(ix.ls);
+      RC(klab_swin_attn_bwd(&a, c.ws()));
+      RC(klab_swin_cpb_bias_bwd(e->sdbias, q.bias, e->swin_index[st], e->swin_coords[st], q.hidden, W[ix.c0w], W[ix.c2w], e->sdtable, G(ix.c0w),
+                                G(ix.c0b), G(ix.c2w), e->swin_ntab[st], n, q.H, 512, c.ws()));
+      if (ix.qb >= 0) {
+        RC(klab_colsum(e->sdqkv, 3 * C, c.dt, M, C, G(ix.qb), c.ws()));
+        RC(klab_colsum((char*)e->sdqkv + (size_t)2 * C * c.es, 3 * C, c.dt, M, C, G(ix.vb), c.ws()));
+      }
+      RC(linear_wgrad(c, e->sdqkv, 3 * C, q.xt_in, C, M, 3 * C, C, G(ix.qw)));  // q|k|v grads adjacent
+      {
+        klab_gemm_args g = G0(c, M, C, 3 * C, e->sdqkv, 3 * C, 1, woff(c, P[ix.qw].warena_off), C, 0, dh, C, KLAB_F32);
+        g.accumulate = 1;
+        RC(klab_gemm(&g, c.ws()));
+      }
+    }
+  }
+  // patch embedding: LN -> conv-as-GEMM (weights + bias only; pixels need no gradient)
+  const long M0 = (long)B * R0 * R0;
+  const int K0 = s.in_ch * s.patch * s.patch;
+  RC(klab_layernorm_bwd(dh, e->pe_out, c.dt, W[e->si.penw], e->pe_mean, e->pe_rstd, e->sdy, G(e->si.penw), G(e->si.penb), (int)M0, C0, 0, 0, 0,
+                        0.f, nullptr, 0, c.ws()));
+  RC(klab_colsum(e->sdy, C0, c.dt, (int)M0, C0, G(e->si.peb), c.ws()));
+  RC(linear_wgrad(c, e->sdy, C0, e->cols, K0, (int)M0, C0, K0, G(e->si.pew)));
+  return 0;
+}
+
+}  // namespace

@@ -259,6 +259,19 @@ __global__ __launch_bounds__(256) void add_f32_kernel(float* __restrict__ y, con
   }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long n) {
+  constexpr int VEC = Vec16<T>::N;
+  using VT = typename Vec16<T>::type;
+  for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < n / VEC; g += (long)gridDim.x * blockDim.x) {
+    VT v = *reinterpret_cast<const VT*>(x + g * VEC);
+    VT o;
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) o[u] = from_f32<T>(gelu_erf(to_f32(v[u])));
+    *reinterpret_cast<VT*>(y + g * VEC) = o;
+  }
+}
+
 static inline unsigned stream_grid(long work_items) {
   long g = (work_items + 255) / 256;
   if (g < 1) g = 1;
@@ -388,6 +401,15 @@ extern "C" int klab_convert(const float* x, void* y, int dtype, long n, float sc
 extern "C" int klab_add_f32(float* y, const float* x, long n, void* stream) {
   if (!x || !y || (n & 3)) return KLAB_ERR_BADARG;
   hipLaunchKernelGGL(add_f32_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, y, x, n / 4);
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+
+extern "C" int klab_gelu_fwd(const void* x, void* y, int dtype, long n, void* stream) {
+  if (!x || !y || (n & 7)) return KLAB_ERR_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == KLAB_BF16) hipLaunchKernelGGL(gelu_fwd_kernel<bf16_t>, dim3(stream_grid(n / 8)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, n);
+  else hipLaunchKernelGGL(gelu_fwd_kernel<float>, dim3(stream_grid(n / 4)), dim3(256), 0, s, (const float*)x, (float*)y, n);
   KLAB_LAUNCH_CHECK();
   return KLAB_OK;
 }

@@ -1,0 +1,316 @@
+"""Drop-in mirror of the reference's `models/model.py::MyModel` (ref/models/model.py:8-42).
+
+Same constructor (`MyModel(args)`), same `forward(images, source_encoding, target_encoding=None,
+return_loss=True)`, same `save` / `load`, same attributes (`.transformer`, `.image_model`,
+`.language_model`) and the same state-dict key schema as the HuggingFace modules the reference
+wraps -- but forward + backward run in the native engine (libklab_mm.so), not in `transformers`.
+`train.py` (ref/train.py) works unchanged: `.to(device)`, `DDP(model)`, `Adam(model.module.
+transformer.parameters())`, `model.module.transformer.train()/eval()`, `loss.item()`,
+`loss.backward()`, `model.module.save(...)`.
+"""
+import os
+from typing import Dict, List, Optional
+
+import torch
+from torch import nn
+
+from .. import hf_io
+from ..engine import Engine, SwinConfig, T5Config
+
+TIED_T5 = ("encoder.embed_tokens.weight", "decoder.embed_tokens.weight", "lm_head.weight")  # HF/t5:902-906
+
+
+class _Node(nn.Module):
+    """anonymous container so that dotted HuggingFace names become real module paths."""
+
+
+class HFTree(nn.Module):
+    """Parameters registered under HuggingFace state-dict names."""
+
+    def __init__(self, specs, tied: Dict[str, str] = None):
+        super().__init__()
+        self._order: List[str] = []
+        for spec in specs:
+            self._register(spec.name, nn.Parameter(torch.empty(spec.shape, dtype=torch.float32)))
+            self._order.append(spec.name)
+        for alias, target in (tied or {}).items():
+            self._register(alias, self.get_parameter(target))
+
+    def _register(self, dotted, param):
+        parts = dotted.split(".")
+        mod = self
+        for p in parts[:-1]:
+            if not hasattr(mod, p):
+                mod.add_module(p, _Node())
+            mod = getattr(mod, p)
+        mod.register_parameter(parts[-1], param)
+
+    def ordered(self):
+        return [self.get_parameter(n) for n in self._order]
+
+
+def _init_t5_(tree: HFTree, cfg: T5Config, gen):
+    """statistics of HF `_init_weights` (HF/t5:562-616), initializer_factor 1."""
+    d, dk, h, ff = cfg.d_model, cfg.d_kv, cfg.num_heads, cfg.d_ff
+    with torch.no_grad():
+        for n, p in tree.named_parameters():
+            if n in TIED_T5:
+                continue
+            if n.endswith("layer_norm.weight"):
+                p.fill_(1.0)
+                continue
+            std = 1.0
+            if n.endswith(".q.weight"):
+                std = (d * dk) ** -0.5
+            elif n.endswith(".k.weight") or n.endswith(".v.weight"):
+                std = d ** -0.5
+            elif n.endswith(".o.weight"):
+                std = (h * dk) ** -0.5
+            elif n.endswith("wi.weight"):
+                std = d ** -0.5
+            elif n.endswith("wo.weight"):
+                std = ff ** -0.5
+            elif n.endswith("relative_attention_bias.weight"):
+                std = d ** -0.5
+            p.copy_(torch.randn(p.shape, generator=gen) * std)
+
+
+def _init_swin_(tree: HFTree, cfg: SwinConfig, gen):
+    """statistics of HF `_init_weights` (HF/swinv2:873-886): N(0, 0.02) weights, zero biases, unit LayerNorm, log(10) scale."""
+    with torch.no_grad():
+        for n, p in tree.named_parameters():
+            if n.endswith("logit_scale"):
+                p.fill_(float(torch.log(torch.tensor(10.0))))
+            elif "norm" in n.split(".")[-2] or n.startswith("layernorm"):
+                p.fill_(1.0 if n.endswith("weight") else 0.0)
+            elif n.endswith("bias"):
+                p.zero_()
+            else:
+                p.copy_(torch.randn(p.shape, generator=gen) * 0.02)
+
+
+class _LossFn(torch.autograd.Function):
+    """autograd boundary: one node for the whole forward; backward runs the engine's segments."""
+
+    @staticmethod
+    def forward(ctx, model, pixels, src, tgt, *params):
+        eng = model._engine_for(pixels, src, tgt)
+        want_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        model._seed_ctr += 1
+        seed = (model._seed_base + 0x9E3779B1 * model._seed_ctr) & 0xFFFFFFFF
+        eng.forward(pixels, src, tgt, training=model.transformer.training, seed=seed, want_grad=want_grad)
+        ctx.model = model
+        ctx.eng = eng
+        ctx.nparams = len(params)
+        model._fwd_token += 1
+        ctx.token = model._fwd_token
+        return eng.loss_view[0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        model, eng = ctx.model, ctx.eng
+        if ctx.token != model._fwd_token or eng is not model._engine:
+            raise RuntimeError("klab MyModel: backward() must follow its own forward() (activations live in one workspace)")
+        g = gout.detach().to(torch.float32).contiguous().view(1)
+        direct = model._direct_grads
+        targets = model._grad_targets()
+        accumulate = direct and any(p.grad is not None for p, _ in targets)
+        saved = None
+        if accumulate:  # .grad aliases the flat buffers the engine is about to overwrite: keep the running sums
+            saved = {m: model._flat[m].clone() for m in ("main", "swin") if model._flat.get(m) is not None}
+        nseg = 3 if model.args.image_model_train else 2
+        for seg in range(nseg):
+            eng.backward(seg, g)
+            if model._segment_hook is not None and not accumulate:
+                model._segment_hook(seg)
+        if accumulate:
+            for m, t in saved.items():
+                model._flat[m].add_(t)
+            if model._segment_hook is not None:
+                for seg in range(nseg):
+                    model._segment_hook(seg)
+        if direct:
+            if not accumulate:
+                for p, view in targets:
+                    p.grad = view
+            return (None,) * (4 + ctx.nparams)
+        grads = []
+        views = {id(p): v for p, v in targets}
+        for p in model._trainable():
+            grads.append(views[id(p)])
+        return (None, None, None, None) + tuple(grads)
+
+
+class MyModel(nn.Module):
+    def __init__(self, args, _configs=None, _state_dicts=None, _seed=0, dtype=None):
+        super().__init__()
+        self.args = args
+        self.result_dir = args.result_dir
+        if _configs is None:
+            lang_cfg, lang_sd = hf_io.resolve(args.language_model_name, "t5")          # ref/models/model.py:14
+            swin_cfg, swin_sd = hf_io.resolve(args.image_model_name, "swin")           # :15
+            main_cfg, main_sd = hf_io.resolve(args.transformer_model_name, "t5")       # :17
+        else:
+            swin_cfg, lang_cfg, main_cfg = _configs
+            swin_sd, lang_sd, main_sd = _state_dicts or (None, None, None)
+        self.swin_cfg, self.lang_cfg, self.main_cfg = swin_cfg, lang_cfg, main_cfg
+        dt = dtype or os.environ.get("KLAB_DTYPE", "bf16")
+        self.compute_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32, torch.bfloat16: torch.bfloat16,
+                              torch.float32: torch.float32}[dt]
+        self._engine = Engine(swin_cfg, lang_cfg, main_cfg, self.compute_dtype, bool(args.image_model_train))
+        tied = {a: "shared.weight" for a in TIED_T5}
+        self.language_model = HFTree(self._engine.params["lang"], {"encoder.embed_tokens.weight": "shared.weight"})
+        self.image_model = HFTree(self._engine.params["swin"])
+        self.transformer = HFTree(self._engine.params["main"], tied)
+        gen = torch.Generator().manual_seed(_seed)
+        for tree, cfg, sd, init in ((self.image_model, swin_cfg, swin_sd, _init_swin_), (self.language_model, lang_cfg, lang_sd, _init_t5_),
+                                    (self.transformer, main_cfg, main_sd, _init_t5_)):
+            if sd is None:
+                init(tree, cfg, gen)
+            else:
+                self._load_tree(tree, sd)
+        self.language_model.requires_grad_(False)                    # ref/models/model.py:14
+        self.image_model.requires_grad_(bool(args.image_model_train))  # :15
+        # from_pretrained returns eval-mode modules and the reference only ever toggles .transformer
+        self.language_model.eval()
+        self.image_model.eval()
+        self.transformer.eval()
+        self._bound_key = None
+        self._flat = {}
+        self._views = None
+        self._direct_grads = False
+        self._segment_hook = None
+        self._seed_base = torch.initial_seed() & 0xFFFFFFFF
+        self._seed_ctr = 0
+        self._fwd_token = 0
+
+    # ---- weights -----------------------------------------------------------------------------
+    @staticmethod
+    def _load_tree(tree, sd):
+        own = tree.state_dict()
+        missing = [k for k in own if k not in sd and k not in TIED_T5 and k != "encoder.embed_tokens.weight"]
+        if "shared.weight" not in sd and "encoder.embed_tokens.weight" in sd:
+            sd = dict(sd)
+            sd["shared.weight"] = sd["encoder.embed_tokens.weight"]
+            missing = [k for k in missing if k != "shared.weight"]
+        if missing:
+            raise RuntimeError(f"Missing key(s) in state_dict: {missing[:5]}{'...' if len(missing) > 5 else ''}")
+        with torch.no_grad():
+            for k, p in tree.named_parameters():
+                if k in sd:
+                    if tuple(sd[k].shape) != tuple(p.shape):
+                        raise RuntimeError(f"size mismatch for {k}: checkpoint {tuple(sd[k].shape)} vs model {tuple(p.shape)}")
+                    p.copy_(sd[k].to(torch.float32))
+
+    def _apply(self, fn, *a, **k):  # .to()/.cuda() replace parameter storage => rebind lazily
+        self._bound_key = None
+        return super()._apply(fn, *a, **k)
+
+    def train(self, mode: bool = True):
+        # nn.Module.train() would flip the frozen towers too; DDP(model) / model.train() callers expect the
+        # reference's effective behaviour only if they call it -- train.py never does (ref/train.py:52 toggles
+        # .transformer only).  Keep torch semantics: propagate, but Swin / language encoder have no train-mode ops here.
+        return super().train(mode)
+
+    # ---- engine plumbing ---------------------------------------------------------------------
+    def _trainable(self):
+        ps = list(self.transformer.ordered())
+        if self.args.image_model_train:
+            ps += list(self.image_model.ordered())
+        return [p for p in ps if p.requires_grad]
+
+    def _engine_for(self, pixels, src, tgt):
+        B, Ls = src.shape
+        Lt = tgt.shape[1]
+        dev = pixels.device
+        if dev.type != "cuda":
+            raise RuntimeError("klab MyModel runs on an MI355X (cuda/HIP device) only; there is no CPU fallback")
+        key = (B, Ls, Lt, dev)
+        if self._bound_key != key:
+            eng = self._engine
+            tensors = {"swin": [p.data for p in self.image_model.ordered()], "lang": [p.data for p in self.language_model.ordered()],
+                       "main": [p.data for p in self.transformer.ordered()]}
+            for ts in tensors.values():
+                for t in ts:
+                    if t.device != dev:
+                        raise RuntimeError(f"Expected all tensors to be on the same device, but found {t.device} and {dev}")
+            if "main" not in self._flat or self._flat["main"].device != dev:
+                self._flat["main"] = torch.zeros(eng.grad_elems["main"], device=dev)
+                self._flat["swin"] = torch.zeros(max(eng.grad_elems["swin"], 8), device=dev) if self.args.image_model_train else None
+                self._views = None
+            eng.bind(B, Ls, Lt, tensors, self._flat["main"], self._flat["swin"], dev)
+            self._bound_key = key
+        return self._engine
+
+    def _grad_targets(self):
+        if self._views is None:
+            out = []
+            for mname, tree in (("main", self.transformer), ("swin", self.image_model)):
+                flat = self._flat.get(mname)
+                if flat is None:
+                    continue
+                for spec, p in zip(self._engine.params[mname], tree.ordered()):
+                    if spec.grad_off >= 0:
+                        out.append((p, flat[spec.grad_off:spec.grad_off + p.numel()].view(p.shape)))
+            self._views = out
+        return [(p, v) for p, v in self._views if p.requires_grad]
+
+    def flat_grads(self, model="main"):
+        return self._flat.get(model)
+
+    # ---- the reference surface -----------------------------------------------------------------
+    def forward(self, images, source_encoding, target_encoding=None, return_loss=True):
+        pixels = images["pixel_values"]
+        src = source_encoding["input_ids"]
+        if pixels.dim() != 4 or pixels.shape[1] != self.swin_cfg.num_channels:
+            raise ValueError("Make sure that the channel dimension of the pixel values match with the one set in the configuration.")
+        if pixels.shape[2] != self.swin_cfg.image_size or pixels.shape[3] != self.swin_cfg.image_size:
+            raise NotImplementedError(f"images must be {self.swin_cfg.image_size}x{self.swin_cfg.image_size} (the configured size)")
+        pixels = pixels.to(torch.float32).contiguous()
+        src = src.to(torch.int64).contiguous()
+        if return_loss:
+            tgt = target_encoding["input_ids"].to(torch.int64).contiguous()
+            return _LossFn.apply(self, pixels, src, tgt, *self._trainable())
+        return self.generate(pixels, src)
+
+    @torch.no_grad()
+    def generate(self, pixels, src, max_length=20):
+        """greedy decoding with HF's default generation settings (ref/models/model.py:28: max_length 20,
+        no sampling): re-runs the engine forward per step (no KV cache yet)."""
+        B = src.shape[0]
+        cfg = self.main_cfg
+        steps = max_length - 1
+        tgt = torch.full((B, steps), cfg.pad_token_id, dtype=torch.int64, device=src.device)
+        done = torch.zeros(B, dtype=torch.bool, device=src.device)
+        was_training = self.transformer.training
+        self.transformer.eval()
+        try:
+            for t in range(steps):
+                eng = self._engine_for(pixels, src, tgt)
+                eng.forward(pixels, src, tgt, training=False, seed=0, want_grad=False)
+                logits = eng.buffer("logits").view(B, steps, -1)[:, t].float()
+                nxt = logits.argmax(-1)
+                nxt = torch.where(done, torch.full_like(nxt, cfg.pad_token_id), nxt)
+                tgt[:, t] = nxt
+                done |= nxt == cfg.eos_token_id
+                if bool(done.all()):
+                    tgt = tgt[:, :t + 1]
+                    break
+        finally:
+            self.transformer.train(was_training)
+        start = torch.full((B, 1), cfg.decoder_start_token_id, dtype=torch.int64, device=src.device)
+        return torch.cat([start, tgt], dim=1)
+
+    def save(self, result_name="best.pth"):
+        result_path = os.path.join(self.args.result_dir, result_name)
+        checkpoints = {'transformer': self.transformer.state_dict()}
+        if self.args.image_model_train:
+            checkpoints['image_model'] = self.image_model.state_dict()
+        torch.save(checkpoints, result_path)
+
+    def load(self, result_name="best.pth"):
+        result_path = os.path.join(self.args.result_dir, result_name)
+        checkpoints = torch.load(result_path)
+        self.transformer.load_state_dict(checkpoints['transformer'])
+        if self.args.image_model_train:
+            self.image_model.load_state_dict(checkpoints['image_model'])
