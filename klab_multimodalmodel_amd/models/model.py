@@ -93,9 +93,8 @@ class _LossFn(torch.autograd.Function):
     """autograd boundary: one node for the whole forward; backward runs the engine's segments."""
 
     @staticmethod
-    def forward(ctx, model, pixels, src, tgt, *params):
+    def forward(ctx, model, want_grad, pixels, src, tgt, *params):
         eng = model._engine_for(pixels, src, tgt)
-        want_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         model._seed_ctr += 1
         seed = (model._seed_base + 0x9E3779B1 * model._seed_ctr) & 0xFFFFFFFF
         eng.forward(pixels, src, tgt, training=model.transformer.training, seed=seed, want_grad=want_grad)
@@ -133,12 +132,12 @@ class _LossFn(torch.autograd.Function):
             if not accumulate:
                 for p, view in targets:
                     p.grad = view
-            return (None,) * (4 + ctx.nparams)
+            return (None,) * (5 + ctx.nparams)
         grads = []
         views = {id(p): v for p, v in targets}
         for p in model._trainable():
             grads.append(views[id(p)])
-        return (None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None) + tuple(grads)
 
 
 class MyModel(nn.Module):
@@ -270,7 +269,10 @@ class MyModel(nn.Module):
         src = src.to(torch.int64).contiguous()
         if return_loss:
             tgt = target_encoding["input_ids"].to(torch.int64).contiguous()
-            return _LossFn.apply(self, pixels, src, tgt, *self._trainable())
+            params = self._trainable()
+            # (grad mode is off inside Function.forward, so decide here whether d logits must be produced)
+            want_grad = torch.is_grad_enabled() and len(params) > 0
+            return _LossFn.apply(self, want_grad, pixels, src, tgt, *params)
         return self.generate(pixels, src)
 
     @torch.no_grad()
