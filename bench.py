@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Caption-training throughput of the native Swin-V2 -> T5 path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = what ref/train.py:58-67 does per iteration: loss = model(images, src, tgt); loss.backward();
+optimizer.step(); optimizer.zero_grad()  -- forward + backward of MyModel (libklab_mm.so engine), the
+gradient all-reduce over RCCL when N > 1 (klab DistributedDataParallel, overlapped per backward
+segment) and the reference's own torch.optim.Adam over transformer.parameters().
+Workload (BASELINE.json configs[1], resolved per SURVEY §8d to a reference-runnable width-matched
+pair): Swin-V2 C=64 (2,2,6,2)/(2,4,8,16) 224x224 w7 frozen + T5-small, bf16 operands with fp32
+accumulation, batch 64 per GPU, Ls=9, Lt=64, T5 dropout 0.1 ON, synthetic inputs already resident
+in HBM, random-init weights (no network).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+GFLOP_PER_SAMPLE = {"cfg2": 27.26}  # fwd+bwd algorithmic work, SURVEY §8d / BASELINE.md §3
+PEAK_BF16_TFLOPS = 2500.0           # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def synth_batch(B, Ls, Lt, H, vocab, device, seed=1234):
+    g = torch.Generator().manual_seed(seed)
+    pix = torch.randn(B, 3, H, H, generator=g)
+    src = torch.randint(2, 32000, (B, Ls), generator=g)
+    tgt = torch.randint(2, 32000, (B, Lt), generator=g)
+    src[:, -1] = 1
+    tgt[:, -1] = 1
+    return pix.to(device), src.to(device), tgt.to(device)
+
+
+def cfg2_configs():
+    from klab_multimodalmodel_amd.engine import SwinConfig, T5Config
+    sw = SwinConfig(image_size=224, embed_dim=64, depths=(2, 2, 6, 2), num_heads=(2, 4, 8, 16), window_size=7)
+    t5 = T5Config()  # t5-small
+    return sw, t5
+
+
+def cpu_baseline(budget_s=20.0):
+    """oracle (CPU restatement of the reference path, oracle/swin_t5_oracle.py) timed on the host cores at
+    BASELINE.json configs[0]: B=2, fp32, T5 dropout on, Adam step included."""
+    from oracle import swin_t5_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(0)
+    sc = O.SwinCfg(image_size=224, embed_dim=64, depths=(2, 2, 6, 2), num_heads=(2, 4, 8, 16), window_size=7)
+    tc = O.T5Cfg()
+    swin_sd = O.hf_like_init_swin(sc, g)
+    lang_sd = O.hf_like_init_t5(tc, g, encoder_only=True)
+    main_sd = {k: v.requires_grad_(True) for k, v in O.hf_like_init_t5(tc, g).items()}
+    opt = torch.optim.Adam(list(main_sd.values()), lr=1e-3)
+    B = 2
+    pix, src, tgt = synth_batch(B, 9, 64, 224, 32128, "cpu")
+    times = []
+    t_all = time.perf_counter()
+    it = 0
+    while True:
+        t0 = time.perf_counter()
+        loss = O.mymodel_forward(swin_sd, lang_sd, main_sd, sc, tc, tc, pix, src, tgt, training=True)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        dt = time.perf_counter() - t0
+        it += 1
+        if it > 2:
+            times.append(dt)
+        if (time.perf_counter() - t_all > budget_s and len(times) >= 3) or len(times) >= 20:
+            break
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(B / med, 3), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fwd+bwd+Adam, configs[0] (B=2, fp32, Ls=9, Lt=64, 224px), median of {len(times)} steps after 2 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE configs[1]: 64)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    if a.gpus != world and dist_on:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from klab_multimodalmodel_amd.models.model import MyModel
+    sw, t5 = cfg2_configs()
+    args = types.SimpleNamespace(result_dir="/tmp", language_model_name="t5-small", image_model_name="swinv2-C64-224-w7",
+                                 image_model_train=False, transformer_model_name="t5-small")
+    torch.manual_seed(0)
+    model = MyModel(args, _configs=(sw, t5, t5), _seed=0, dtype="bf16").to(dev)
+    if dist_on:
+        from klab_multimodalmodel_amd.ddp import DistributedDataParallel as DDP
+        model = DDP(model, device_ids=[local_rank])
+        core = model.module
+    else:
+        core = model
+        core._direct_grads = True  # grads land in the flat buffer (no autograd copies); same math
+    optimizer = torch.optim.Adam(core.transformer.parameters(), lr=1e-3)  # ref/train.py:28
+    core.transformer.train()                                               # ref/train.py:52
+
+    B, Ls, Lt = a.batch, 9, 64
+    pix, src, tgt = synth_batch(B, Ls, Lt, 224, 32128, dev, seed=1234 + rank)
+    images, se, te = {"pixel_values": pix}, {"input_ids": src}, {"input_ids": tgt}
+
+    def step():
+        loss = model(images, se, te)
+        loss.backward()
+        optimizer.step()
+        optimizer.zero_grad()
+        return loss
+
+    for _ in range(a.warmup):
+        step()
+    eng = core._engine
+    eng.probe_enable(True)
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    launches, probe_ms, flops = eng.probe_read()
+    eng.probe_enable(False)
+    lossv = float(loss.item())
+
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        value = world * B * a.steps / dt
+        out = {
+            "metric": "caption-train samples/sec (224px img, 64-tok tgt)", "value": round(value, 2), "unit": "samples/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: Swin-V2(C=64,(2,2,6,2),224,w7) frozen + T5-small, fwd+bwd+Adam, "
+                                   "T5 dropout 0.1 on, random-init weights",
+                       "global_batch": world * B, "per_gpu_batch": B, "src_len": Ls, "tgt_len": Lt,
+                       "parallelism": f"dp{world}", "fwd_bwd_gflop_per_sample": GFLOP_PER_SAMPLE["cfg2"],
+                       "step_mfma_frac": round(B * GFLOP_PER_SAMPLE["cfg2"] / (ms * 1e-3) / 1e3 / PEAK_BF16_TFLOPS, 4),
+                       "final_loss": round(lossv, 4)},
+        }
+        if launches > 0:
+            avg_ms = probe_ms / launches
+            ach = flops / (avg_ms * 1e-3) / 1e12
+            traffic = None
+            tp = os.path.join(ROOT, "profiles", "lmhead_traffic.json")
+            if os.path.exists(tp):
+                try:
+                    traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            out["roofline"] = {"kernel": "klab_lmhead_gemm<bf16> (LM-head logits GEMM [B*Lt, 32128] x d=512)", "bound": "mfma",
+                               "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                               "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches": launches,
+                               "flops_per_launch": flops}
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist_on:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -59,6 +59,7 @@ typedef struct klab_gemm_args {
   const void* aux; long ldaux; int aux_mode; float aux_scale; /* aux: [M,N] in `dtype` */
   const void* residual; long ldr; int r_dtype;                /* added last */
   float drop_p; const uint32_t* seed_dev; uint32_t drop_tag;  /* dropout before the residual */
+  int name_tag; /* 1: launch under the symbol klab_lmhead_gemm (128x128 NT tile) so profiles can single it out */
 } klab_gemm_args;
 int klab_gemm(const klab_gemm_args* args, void* stream);
 
@@ -213,6 +214,10 @@ int klab_engine_forward(klab_engine* e, const float* pixels, const long long* sr
 /* segment 0: LM head + decoder + tied embedding; 1: encoder; 2: Swin (no-op unless train_swin).
  * dloss_dev: device scalar d(objective)/d(loss) (NULL = 1).                                       */
 int klab_engine_backward(klab_engine* e, int segment, const float* dloss_dev, void* stream);
+/* timing probe on the dominant kernel (the LM-head logits GEMM, symbol klab_lmhead_gemm): when enabled, every
+ * forward brackets that launch with two HIP events on the compute stream; read back after a synchronize.   */
+int klab_engine_probe_enable(klab_engine* e, int on);
+int klab_engine_probe_read(klab_engine* e, int* launches, float* total_ms, double* flops_per_launch);
 const float* klab_engine_loss_ptr(const klab_engine* e);
 const int* klab_engine_err_ptr(const klab_engine* e);
 const void* klab_engine_buffer(const klab_engine* e, const char* name, long* rows, long* cols, int* dtype);

@@ -114,6 +114,8 @@ struct klab_engine {
   // swin backward scratch
   float *sdh_a = nullptr, *sdh_b = nullptr, *sdm = nullptr; void *sdy = nullptr, *sdctx = nullptr, *sdqkv = nullptr, *sda = nullptr;
   float *sdbias = nullptr, *sdtable = nullptr;
+  // probe: HIP events around the LM-head GEMM of each forward
+  bool probe_on = false; std::vector<hipEvent_t> ev0, ev1; int probe_n = 0;
   float p_train = 0.f;   // dropout prob in effect for the last forward (0 in eval)
   const long long* last_tgt = nullptr;
 };
@@ -870,12 +872,42 @@ extern "C" int klab_engine_forward(klab_engine* e, const float* pixels, const lo
     const int Md = B * e->Lt, V = cfg.main.vocab;
     klab_gemm_args g = G0(c, Md, V, d, e->dec.out_t, d, 1, woff(c, e->P[2][e->mi.shared].warena_off), d, 1, e->logits, V, c.dt);
     g.alpha = cfg.main.scale_decoder_outputs ? 1.f / sqrtf((float)d) : 1.f;  // HF/t5:1044-1045
+    g.name_tag = 1;
+    const bool probe = e->probe_on && e->probe_n < (int)e->ev0.size();
+    if (probe) RC((int)hipEventRecord(e->ev0[e->probe_n], c.s));
     RC(klab_gemm(&g, c.ws()));
+    if (probe) { RC((int)hipEventRecord(e->ev1[e->probe_n], c.s)); ++e->probe_n; }
     RC(klab_ce_fwd(e->logits, V, c.dt, tgt_ids, Md, V, e->inv_n, e->loss_row, e->loss, want_grad, c.ws()));
   }
   return 0;
 }
 
+extern "C" int klab_engine_probe_enable(klab_engine* e, int on) {
+  if (!e) return KLAB_ERR_BADARG;
+  if (on && e->ev0.empty()) {
+    e->ev0.resize(512); e->ev1.resize(512);
+    for (size_t i = 0; i < e->ev0.size(); ++i) {
+      if (hipEventCreate(&e->ev0[i]) != hipSuccess || hipEventCreate(&e->ev1[i]) != hipSuccess) return KLAB_ERR_UNSUPPORTED;
+    }
+  }
+  e->probe_on = on != 0;
+  e->probe_n = 0;
+  return 0;
+}
+extern "C" int klab_engine_probe_read(klab_engine* e, int* launches, float* total_ms, double* flops_per_launch) {
+  if (!e) return KLAB_ERR_BADARG;
+  float tot = 0.f;
+  for (int i = 0; i < e->probe_n; ++i) {
+    float ms = 0.f;
+    hipError_t er = hipEventElapsedTime(&ms, e->ev0[i], e->ev1[i]);
+    if (er != hipSuccess) return (int)er;
+    tot += ms;
+  }
+  if (launches) *launches = e->probe_n;
+  if (total_ms) *total_ms = tot;
+  if (flops_per_launch) *flops_per_launch = 2.0 * (double)e->B * e->Lt * (double)e->cfg.main.vocab * (double)e->cfg.main.d_model;
+  return 0;
+}
 extern "C" const float* klab_engine_loss_ptr(const klab_engine* e) { return e ? e->loss : nullptr; }
 extern "C" const int* klab_engine_err_ptr(const klab_engine* e) { return e ? e->err_dev : nullptr; }
 

@@ -96,8 +96,10 @@ struct Stager {
   }
 };
 
+// NAMETAG only gives the LM-head launch its own symbol (klab_lmhead_gemm) so that profiles and the
+// in-process probe (klab_engine_probe) can be matched kernel for kernel.
 template <typename T, int BM, int BN, bool AK, bool BKM>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
+__device__ __forceinline__ void gemm_body(const GemmP& p) {
   constexpr int BK = MmaTraits<T>::BK;
   constexpr int WTM = BM / 2, WTN = BN / 2;  // wave tile (2x2 waves)
   constexpr int MI = WTM / 16, NI = WTN / 16;
@@ -241,6 +243,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 }
 
 template <typename T, int BM, int BN, bool AK, bool BKM>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmP p) { gemm_body<T, BM, BN, AK, BKM>(p); }
+template <typename T>
+__global__ __launch_bounds__(256) void klab_lmhead_gemm(GemmP p) { gemm_body<T, 128, 128, true, true>(p); }
+
+template <typename T, int BM, int BN, bool AK, bool BKM>
 static int launch_gemm(const GemmP& p, hipStream_t s) {
   const size_t lds = 2 * (size_t)(BM + BN) * ROWB;
   static bool attr_set = false;
@@ -251,6 +258,22 @@ static int launch_gemm(const GemmP& p, hipStream_t s) {
     attr_set = true;
   }
   const int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tm * tn)), dim3(256), lds, s, p);
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+
+template <typename T>
+static int launch_lmhead(const GemmP& p, hipStream_t s) {
+  const size_t lds = 2 * (size_t)(128 + 128) * ROWB;
+  static bool attr_set = false;
+  auto kern = klab_lmhead_gemm<T>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int tm = (p.M + 127) / 128, tn = (p.N + 127) / 128;
   hipLaunchKernelGGL(kern, dim3((unsigned)(tm * tn)), dim3(256), lds, s, p);
   KLAB_LAUNCH_CHECK();
   return KLAB_OK;
@@ -295,6 +318,8 @@ extern "C" int klab_gemm(const klab_gemm_args* a, void* stream) {
   if (a->dtype != KLAB_F32 && a->dtype != KLAB_BF16) return KLAB_ERR_BADARG;
   if (a->c_dtype != KLAB_F32 && a->c_dtype != a->dtype) return KLAB_ERR_BADARG;
   hipStream_t s = (hipStream_t)stream;
+  if (a->name_tag == 1 && a->a_kmajor && a->b_kmajor)
+    return a->dtype == KLAB_BF16 ? launch_lmhead<bf16_t>(p, s) : launch_lmhead<float>(p, s);
   if (a->dtype == KLAB_BF16) return dispatch_tile<bf16_t>(p, s);
   return dispatch_tile<float>(p, s);
 }

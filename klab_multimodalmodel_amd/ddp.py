@@ -1,0 +1,106 @@
+"""Data parallelism for the native MyModel: the reference's only parallel strategy
+(`DDP(model, device_ids=[device_id])`, ref/train.py:26), re-done for MI355X.
+
+The engine writes gradients into flat fp32 buffers whose layout follows the backward order
+(segment 0 = LM head + decoder + tied embedding, 1 = encoder, 2 = Swin).  When a segment's kernels
+have been enqueued, its slice of the flat buffer is all-reduced IN PLACE (no bucket copies) by RCCL
+on a side HIP stream, overlapping the next segment's backward; the last reduce is joined before
+`optimizer.step()`.  One process per GPU; `backend="nccl"` is RCCL over xGMI on ROCm.
+Semantics kept from torch DDP: parameters broadcast from rank 0 at construction, gradients averaged
+over ranks, every micro-step reduces (the reference never uses no_sync).
+"""
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+
+class SegmentReducer:
+    """All-reduce (mean) of slices of flat gradient buffers, asynchronously, in launch order.
+
+    Device-agnostic so that the bucket logic is testable with gloo on CPU; on GPU the collective runs
+    on `comm_stream` behind an event recorded on the compute stream."""
+
+    def __init__(self, segments: List[Tuple[str, int, int]], process_group=None, max_bucket_elems: int = 64 << 20):
+        self.segments = segments
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.max_bucket = max_bucket_elems
+        self.comm_stream: Optional[torch.cuda.Stream] = None
+        self._works = []
+        backend = dist.get_backend(process_group) if dist.is_initialized() else ""
+        self._avg_op = dist.ReduceOp.AVG if backend == "nccl" else None
+
+    def buckets(self, seg: int):
+        """(model, offset, length) pieces of a segment: large segments are cut so that RCCL can start
+        on the first piece while the rest is still being enqueued/transferred."""
+        model, off, ln = self.segments[seg]
+        out = []
+        while ln > 0:
+            n = min(ln, self.max_bucket)
+            out.append((model, off, n))
+            off += n
+            ln -= n
+        return out
+
+    def reduce_segment(self, seg: int, flats):
+        if self.world == 1:
+            return
+        for model, off, n in self.buckets(seg):
+            flat = flats.get(model)
+            if flat is None or n == 0:
+                continue
+            t = flat[off:off + n]
+            if t.is_cuda:
+                if self.comm_stream is None:
+                    self.comm_stream = torch.cuda.Stream(device=t.device)
+                self.comm_stream.wait_stream(torch.cuda.current_stream(t.device))
+                with torch.cuda.stream(self.comm_stream):
+                    if self._avg_op is not None:
+                        dist.all_reduce(t, op=self._avg_op, group=self.pg)
+                    else:
+                        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+                        t.div_(self.world)
+            else:
+                w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                self._works.append((w, t))
+
+    def finish(self, device=None):
+        """join: after this the compute stream may consume the averaged gradients."""
+        for w, t in self._works:
+            w.wait()
+            t.div_(self.world)
+        self._works = []
+        if self.comm_stream is not None:
+            torch.cuda.current_stream(device).wait_stream(self.comm_stream)
+
+
+class DistributedDataParallel(nn.Module):
+    """Drop-in for `torch.nn.parallel.DistributedDataParallel(model, device_ids=[...])` around the
+    native MyModel (`.module`, `forward(*args)`), with segment-overlapped gradient reduction."""
+
+    def __init__(self, module, device_ids=None, process_group=None, broadcast_parameters=True, max_bucket_elems=64 << 20):
+        super().__init__()
+        self.module = module
+        self.process_group = process_group
+        self.device_ids = device_ids
+        eng = module._engine
+        nseg = 3 if module.args.image_model_train else 2
+        self.reducer = SegmentReducer(eng.segments[:nseg], process_group, max_bucket_elems)
+        self._nseg = nseg
+        module._direct_grads = True
+        module._segment_hook = self._on_segment
+        if broadcast_parameters and dist.is_initialized() and dist.get_world_size(process_group) > 1:
+            with torch.no_grad():  # torch DDP's _sync_module_states (TORCH/ddp:864-867)
+                for p in module.parameters():
+                    dist.broadcast(p.data, src=0, group=process_group)
+
+    def _on_segment(self, seg):
+        flats = {"main": self.module._flat.get("main"), "swin": self.module._flat.get("swin")}
+        self.reducer.reduce_segment(seg, flats)
+        if seg == self._nseg - 1:
+            self.reducer.finish()
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)

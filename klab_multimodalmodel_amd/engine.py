@@ -113,6 +113,8 @@ ENGINE_SIGS = {
                           C.POINTER(C.c_void_p), C.c_void_p], C.c_int),
     "klab_engine_forward": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_void_p], C.c_int),
     "klab_engine_backward": ([C.c_void_p, C.c_int, C.c_void_p, C.c_void_p], C.c_int),
+    "klab_engine_probe_enable": ([C.c_void_p, C.c_int], C.c_int),
+    "klab_engine_probe_read": ([C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_double)], C.c_int),
     "klab_engine_loss_ptr": ([C.c_void_p], C.c_void_p),
     "klab_engine_err_ptr": ([C.c_void_p], C.c_void_p),
     "klab_engine_buffer": ([C.c_void_p, C.c_char_p, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_int)], C.c_void_p),
@@ -323,6 +325,15 @@ class Engine:
     def backward(self, segment, dloss=None):
         L.check(self._lib.klab_engine_backward(self._h, segment, dloss.data_ptr() if dloss is not None else None, L.stream_ptr()),
                 "klab_engine_backward")
+
+    def probe_enable(self, on=True):
+        L.check(self._lib.klab_engine_probe_enable(self._h, int(on)), "klab_engine_probe_enable")
+
+    def probe_read(self):
+        """(launches, total_ms, flops_per_launch) of the LM-head GEMM since probe_enable(); call after a synchronize."""
+        n, ms, fl = C.c_int(), C.c_float(), C.c_double()
+        L.check(self._lib.klab_engine_probe_read(self._h, C.byref(n), C.byref(ms), C.byref(fl)), "klab_engine_probe_read")
+        return n.value, ms.value, fl.value
 
     def buffer(self, name):
         rows, cols, dt = C.c_long(), C.c_long(), C.c_int()

@@ -123,3 +123,52 @@ def test_width_mismatch_raises_like_the_reference():
                                  transformer_model_name="-")
     with pytest.raises(RuntimeError, match="Sizes of tensors must match"):
         MyModel(args, _configs=(SwinConfig(embed_dim=96), T5Config(), T5Config()))  # Swin-Tiny 768 vs t5-small 512
+
+
+def _oracle_from_model(m):
+    from oracle import swin_t5_oracle as O
+    sc = O.SwinCfg(**{k: getattr(m.swin_cfg, k) for k in O.SwinCfg.__dataclass_fields__})
+    def t5(c):
+        return O.T5Cfg(**{k: getattr(c, k) for k in O.T5Cfg.__dataclass_fields__ if hasattr(c, k)})
+    sds = []
+    for tree in (m.image_model, m.language_model, m.transformer):
+        sds.append({k: v.detach().cpu().clone() for k, v in tree.state_dict().items()})
+    return O, sc, t5(m.lang_cfg), t5(m.main_cfg), sds
+
+
+@pytest.mark.parametrize("dtype,loss_tol,cos_min", [(torch.float32, 2e-5, 0.99999), (torch.bfloat16, 2e-3, 0.99)])
+def test_full_size_architecture_matches_oracle(dtype, loss_tol, cos_min):
+    """BASELINE configs[0]/[1] architecture (Swin-V2 C=64 (2,2,6,2) 224 w7 + T5-small, V=32128) at B=2:
+    exercises n=49 windows, head dim 32, the 128x128 GEMM tiles and the 32128-wide LM head."""
+    from klab_multimodalmodel_amd.engine import SwinConfig, T5Config
+    from klab_multimodalmodel_amd.models.model import MyModel
+    sw = SwinConfig(image_size=224, embed_dim=64, depths=(2, 2, 6, 2), num_heads=(2, 4, 8, 16), window_size=7)
+    t5 = T5Config()
+    args = types.SimpleNamespace(result_dir="/tmp", language_model_name="-", image_model_name="-", image_model_train=False,
+                                 transformer_model_name="-")
+    m = MyModel(args, _configs=(sw, t5, t5), _seed=3, dtype=dtype)
+    O, sc, lc, mc, (ssd, lsd, msd) = _oracle_from_model(m)
+    m = m.to("cuda")
+    m.transformer.eval()
+    g = torch.Generator().manual_seed(1234)
+    B, Ls, Lt = 2, 9, 64
+    pix = torch.randn(B, 3, 224, 224, generator=g)
+    src = torch.randint(2, 32000, (B, Ls), generator=g)
+    tgt = torch.randint(2, 32000, (B, Lt), generator=g)
+    src[:, -1] = 1
+    tgt[:, -1] = 1
+    tgt[1, -16:] = 0  # pad tail: pads are scored (SURVEY §0.4)
+    loss = m({"pixel_values": pix.cuda()}, {"input_ids": src.cuda()}, {"input_ids": tgt.cuda()})
+    loss.backward()
+    msd = {k: v.requires_grad_(True) for k, v in msd.items()}
+    torch.set_num_threads(8)
+    ref = O.mymodel_forward(ssd, lsd, msd, sc, lc, mc, pix, src, tgt, training=False)
+    ref.backward()
+    assert abs(loss.item() - float(ref)) <= loss_tol * abs(float(ref)), (loss.item(), float(ref))
+    a, b = [], []
+    for k, p in m.transformer.named_parameters():
+        a.append(p.grad.cpu().flatten())
+        b.append(msd[k].grad.flatten())
+    c = cosine(torch.cat(a), torch.cat(b))
+    print("full-size", dtype, "loss", loss.item(), float(ref), "grad cosine", c, "rel-L2", rel_l2(torch.cat(a), torch.cat(b)))
+    assert c > cos_min
