@@ -46,11 +46,24 @@ def cfg2_configs():
     return sw, t5
 
 
+def usable_cores():
+    """host cores this process may actually use: affinity mask capped by the cgroup CPU quota (a GPU box
+    exposes far more logical CPUs than its share; oversubscribing OpenMP threads would only time spinning)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("KLAB_CPU_BASELINE_THREADS", "16"))))
+
+
 def cpu_baseline(budget_s=20.0):
     """oracle (CPU restatement of the reference path, oracle/swin_t5_oracle.py) timed on the host cores at
     BASELINE.json configs[0]: B=2, fp32, T5 dropout on, Adam step included."""
     from oracle import swin_t5_oracle as O
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(0)
     sc = O.SwinCfg(image_size=224, embed_dim=64, depths=(2, 2, 6, 2), num_heads=(2, 4, 8, 16), window_size=7)
@@ -181,6 +194,7 @@ def main():
                                "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                                "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches": launches,
                                "flops_per_launch": flops}
+        print(f"[bench] gpu leg done: {value:.1f} samples/s, {ms:.2f} ms/step", file=sys.stderr, flush=True)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
