@@ -60,6 +60,8 @@ typedef struct klab_gemm_args {
   const void* residual; long ldr; int r_dtype;                /* added last */
   float drop_p; const uint32_t* seed_dev; uint32_t drop_tag;  /* dropout before the residual */
   int name_tag; /* 1: launch under the symbol klab_lmhead_gemm (128x128 NT tile) so profiles can single it out */
+  int atomic_ok; /* with accumulate=1 and a plain f32 product: the kernel may split K and add partial sums with
+                    float atomics (summation order, hence the last bits, then vary run to run) */
 } klab_gemm_args;
 int klab_gemm(const klab_gemm_args* args, void* stream);
 

@@ -24,7 +24,7 @@ class GemmArgs(C.Structure):
                 ("alpha", f32), ("alpha_dev", vp), ("bias", vp), ("act", i32),
                 ("aux", vp), ("ldaux", i64), ("aux_mode", i32), ("aux_scale", f32),
                 ("residual", vp), ("ldr", i64), ("r_dtype", i32),
-                ("drop_p", f32), ("seed_dev", vp), ("drop_tag", u32), ("name_tag", i32)]
+                ("drop_p", f32), ("seed_dev", vp), ("drop_tag", u32), ("name_tag", i32), ("atomic_ok", i32)]
 
 
 class AttnArgs(C.Structure):

@@ -483,6 +483,7 @@ int linear_dgrad(const Ctx& c, const void* dy, long lddy, int M, int N, long wof
 // dW[N,K] = dY[M,N]^T @ X[M,K]  -> f32 grads
 int linear_wgrad(const Ctx& c, const void* dy, long lddy, const void* x, long ldx, int M, int N, int K, float* dw) {
   klab_gemm_args g = G0(c, N, K, M, dy, lddy, 0, x, ldx, 0, dw, K, KLAB_F32);
+  g.accumulate = 1; g.atomic_ok = 1;  // the segment's grad slice was zeroed: small outputs may split K
   return klab_gemm(&g, c.ws());
 }
 
@@ -931,7 +932,7 @@ extern "C" int klab_engine_backward(klab_engine* e, int segment, const float* dl
   const float p = e->p_train;
   float* Gm = e->G[2];
   if (segment == 0) {
-    RC((int)hipMemsetAsync(Gm + e->seg_zero_off[0], 0, (size_t)e->seg_zero_len[0] * 4, c.s));
+    RC((int)hipMemsetAsync(Gm + e->seg_off[0], 0, (size_t)e->seg_len[0] * 4, c.s));
     const int Md = B * e->Lt, V = cfg.main.vocab;
     const float alpha = cfg.main.scale_decoder_outputs ? 1.f / sqrtf((float)d) : 1.f;
     {  // d(dec_out) [Md,d] = dlogits [Md,V] @ shared [V,d]
@@ -941,7 +942,7 @@ extern "C" int klab_engine_backward(klab_engine* e, int segment, const float* dl
     }
     {  // d shared [V,d] = dlogits^T @ dec_out  (first of the tied weight's three contributors)
       klab_gemm_args g = G0(c, V, d, Md, e->logits, V, 0, e->dec.out_t, d, 0, Gm + e->P[2][e->mi.shared].grad_off, d, KLAB_F32);
-      g.alpha = alpha; g.alpha_dev = dloss_dev;
+      g.alpha = alpha; g.alpha_dev = dloss_dev; g.accumulate = 1; g.atomic_ok = 1;
       RC(klab_gemm(&g, c.ws()));
     }
     float* dh0 = nullptr;
@@ -957,7 +958,7 @@ extern "C" int klab_engine_backward(klab_engine* e, int segment, const float* dl
     return 0;
   }
   if (segment == 1) {
-    RC((int)hipMemsetAsync(Gm + e->seg_zero_off[1], 0, (size_t)e->seg_zero_len[1] * 4, c.s));
+    RC((int)hipMemsetAsync(Gm + e->seg_off[1], 0, (size_t)e->seg_len[1] * 4, c.s));
     // the stack consumes dxn as d(final-norm output)
     const int Me = B * e->Le;
     RC((int)hipMemcpyAsync(e->dxn, e->denc, (size_t)Me * d * 4, hipMemcpyDeviceToDevice, c.s));
@@ -986,7 +987,7 @@ int swin_backward(const Ctx& c, const float* dh0, float p_in) {
   float* Gs = e->G[0];
   auto G = [&](int pi) { return Gs + P[pi].grad_off; };
   const int B = e->B, R0 = s.image_size / s.patch, C0 = s.embed_dim;
-  RC((int)hipMemsetAsync(Gs + e->seg_zero_off[2], 0, (size_t)e->seg_zero_len[2] * 4, c.s));
+  RC((int)hipMemsetAsync(Gs + e->seg_off[2], 0, (size_t)e->seg_len[2] * 4, c.s));
   // final LN backward: input x = last hidden (f32), dout in the remapped encoder-input rows, with the input dropout
   const int last = s.n_stages - 1;
   const int Cl = C0 << last;

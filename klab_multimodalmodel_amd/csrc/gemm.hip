@@ -11,6 +11,9 @@
 // Epilogue (all optional, in this order): *alpha(*alpha_dev) -> +bias[n] -> act (relu | erf-gelu)
 //   -> *gelu'(aux) or *(aux!=0)*aux_scale (backward of gelu / of relu+dropout) -> dropout(seed,tag,p)
 //   -> +residual -> (+C if accumulate) -> store as f32 or as the input dtype.
+#include <map>
+#include <mutex>
+
 #include "common.h"
 #include "klab_mm.h"
 
@@ -37,21 +40,41 @@ struct GemmP {
   const void* aux; long ldaux; int aux_mode; float aux_scale;  // aux has the input dtype
   const void* residual; long ldr; int r_f32;
   float drop_p; const uint32_t* seed; uint32_t tag;
+  int splits;
 };
 
-constexpr int ROWB = 144;  // LDS row pitch in bytes: 128 B of K + one 16-B pad (conflict-free b128 reads)
+constexpr int ROWB = 144;  // K-major LDS row pitch in bytes: 128 B of K + one 16-B pad (conflict-free b128 reads)
 
-// stage one operand tile (ROWS x BK) from global into registers
+// ---- LDS image of an m-major bf16 operand tile (contraction dim is the SLOW global dim) ------------
+// The tile is kept exactly as it is loaded -- rows = 64 k's, columns = ROWS m's (16-B chunks of 8 m go
+// in with one ds_write_b128) -- and the MFMA fragments come out through ds_read_b64_tr_b16, the gfx950
+// hardware transpose read: per 16-lane group a 4(k) x 16(m) block is delivered so that lane i holds
+// 4 consecutive k of column m0+i, i.e. half of the 16x16x32 A/B fragment.  Bank-conflict-free placement:
+// row pitch PD dwords with PD/8 odd (k&7 -> eight distinct 8-dword slots) and every group of 8 k-rows
+// displaced by 32 more dwords, so the two groups a 32-lane half touches (k-rows 8g.. and 8g+8..) split
+// the 64 banks between them.
+template <int ROWS> struct TrLayout {
+  static constexpr int PD = (ROWS == 128) ? 72 : (ROWS == 64 ? 40 : 24);  // dwords; >= ROWS/2, PD/8 odd
+  static constexpr int PITCHB = PD * 4;
+  static constexpr int GROUPB = (8 * PD + 32) * 4;  // bytes per group of 8 k-rows
+  static constexpr int BYTES = 8 * GROUPB;          // 64 k-rows
+};
+
+template <typename T, int ROWS, bool KMAJOR> struct TileBytes { static constexpr int value = ROWS * ROWB; };
+template <int ROWS> struct TileBytes<bf16_t, ROWS, false> { static constexpr int value = TrLayout<ROWS>::BYTES; };
+
+// stage one operand tile (ROWS x BK) from global into registers, then into LDS
 template <typename T, int ROWS, bool KMAJOR>
 struct Stager {
   using V = typename Vec16<T>::type;
   static constexpr int VEC = Vec16<T>::N;
   static constexpr int BK = MmaTraits<T>::BK;
   static constexpr int NCH = ROWS * 8 / 256;             // 16-B chunks per thread
-  static constexpr int KPT = ROWS * BK / (256 * VEC);    // m-major: k's per thread (== NCH)
+  static constexpr int KPT = ROWS * BK / (256 * VEC);    // fp32 m-major: k's per thread (== NCH)
+  static constexpr bool TR = (!KMAJOR) && sizeof(T) == 2;
   V v[NCH];
 
-  __device__ __forceinline__ void load(const T* __restrict__ base, long ld, int row0, int k0, int nrows, int K, int tid) {
+  __device__ __forceinline__ void load(const T* __restrict__ base, long ld, int row0, int k0, int nrows, int kend, int tid) {
     if constexpr (KMAJOR) {
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
@@ -59,7 +82,18 @@ struct Stager {
         int r = ch >> 3, kc = ch & 7;
         int gr = row0 + r, gk = k0 + kc * VEC;
         V z = {};
-        if (gr < nrows && gk < K) z = *reinterpret_cast<const V*>(base + (long)gr * ld + gk);
+        if (gr < nrows && gk < kend) z = *reinterpret_cast<const V*>(base + (long)gr * ld + gk);
+        v[c] = z;
+      }
+    } else if constexpr (TR) {
+      constexpr int CPR = ROWS / 8;  // chunks per k-row
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        int ch = tid + c * 256;
+        int kk = ch / CPR, m8 = ch % CPR;
+        int gk = k0 + kk, gr = row0 + m8 * 8;
+        V z = {};
+        if (gr < nrows && gk < kend) z = *reinterpret_cast<const V*>(base + (long)gk * ld + gr);
         v[c] = z;
       }
     } else {
@@ -70,7 +104,7 @@ struct Stager {
       for (int c = 0; c < KPT; ++c) {
         int gk = k0 + kg * KPT + c;
         V z = {};
-        if (gr < nrows && gk < K) z = *reinterpret_cast<const V*>(base + (long)gk * ld + gr);
+        if (gr < nrows && gk < kend) z = *reinterpret_cast<const V*>(base + (long)gk * ld + gr);
         v[c] = z;
       }
     }
@@ -82,6 +116,15 @@ struct Stager {
         int ch = tid + c * 256;
         int r = ch >> 3, kc = ch & 7;
         *reinterpret_cast<V*>(lds + r * ROWB + kc * 16) = v[c];
+      }
+    } else if constexpr (TR) {
+      constexpr int CPR = ROWS / 8;
+      using TL = TrLayout<ROWS>;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        int ch = tid + c * 256;
+        int kk = ch / CPR, m8 = ch % CPR;
+        *reinterpret_cast<V*>(lds + (kk >> 3) * TL::GROUPB + (kk & 7) * TL::PITCHB + m8 * 16) = v[c];
       }
     } else {
       constexpr int RG = ROWS / VEC;
@@ -96,21 +139,42 @@ struct Stager {
   }
 };
 
-// NAMETAG only gives the LM-head launch its own symbol (klab_lmhead_gemm) so that profiles and the
-// in-process probe (klab_engine_probe) can be matched kernel for kernel.
-template <typename T, int BM, int BN, bool AK, bool BKM>
+// bf16 fragment (8 consecutive k of one row) for k-step ks of 32, row r0 + (lane & 15)
+template <int ROWS, bool KMAJOR>
+__device__ __forceinline__ bf16x8 load_frag_bf16(const char* tile, int r0, int ks, int lane) {
+  if constexpr (KMAJOR) {
+    return *reinterpret_cast<const bf16x8*>(tile + (r0 + (lane & 15)) * ROWB + ks * 64 + (lane >> 4) * 16);
+  } else {
+    using TL = TrLayout<ROWS>;
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    const int q = (lane & 15) >> 2, pp = lane & 3;
+    const char* base = tile + (ks * 4 + (lane >> 4)) * TL::GROUPB + q * TL::PITCHB + (r0 + 4 * pp) * 2;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base + 4 * TL::PITCHB));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  }
+}
+
+
+// One workgroup = 4 waves (2x2) computing a BM x BN tile over k-tiles [kt0, kt1).
+// ATOMIC: split-K partial sums are added to a pre-zeroed / accumulating f32 C with float atomics; the
+// MFMA operands are then NOT swapped so that each atomic wave-instruction covers 16 consecutive n (64 B).
+template <typename T, int BM, int BN, bool AK, bool BKM, bool ATOMIC>
 __device__ __forceinline__ void gemm_body(const GemmP& p) {
   constexpr int BK = MmaTraits<T>::BK;
   constexpr int WTM = BM / 2, WTN = BN / 2;  // wave tile (2x2 waves)
   constexpr int MI = WTM / 16, NI = WTN / 16;
+  constexpr int ABYTES = TileBytes<T, BM, AK>::value, BBYTES = TileBytes<T, BN, BKM>::value;
+  constexpr int STAGE = ABYTES + BBYTES;  // one pipeline stage: A tile then B tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int STAGE = (BM + BN) * ROWB;  // one pipeline stage: A tile then B tile
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave >> 1) * WTM, wn = (wave & 1) * WTN;
-  const int tiles_m = (p.M + BM - 1) / BM;
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  const int tiles = tiles_m * tiles_n;
+  const int tile = blockIdx.x % tiles, split = blockIdx.x / tiles;
   // m-fastest block order: consecutive blocks share one B (weight) panel
-  const int bm0 = (blockIdx.x % tiles_m) * BM, bn0 = (blockIdx.x / tiles_m) * BN;
+  const int bm0 = (tile % tiles_m) * BM, bn0 = (tile / tiles_m) * BN;
 
   const T* A = reinterpret_cast<const T*>(p.A);
   const T* B = reinterpret_cast<const T*>(p.B);
@@ -123,37 +187,44 @@ __device__ __forceinline__ void gemm_body(const GemmP& p) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nt = (p.K + BK - 1) / BK;
-  sa.load(A, p.lda, bm0, 0, p.M, p.K, tid);
-  sb.load(B, p.ldb, bn0, 0, p.N, p.K, tid);
+  const int nt_all = (p.K + BK - 1) / BK;
+  const int per = (nt_all + p.splits - 1) / p.splits;
+  const int kt0 = split * per, kt1 = (kt0 + per < nt_all) ? kt0 + per : nt_all;
+  const int nt = kt1 - kt0;
+  if (nt <= 0) return;
+  sa.load(A, p.lda, bm0, kt0 * BK, p.M, p.K, tid);
+  sb.load(B, p.ldb, bn0, kt0 * BK, p.N, p.K, tid);
   sa.store(smem, tid);
-  sb.store(smem + BM * ROWB, tid);
+  sb.store(smem + ABYTES, tid);
   __syncthreads();
 
   for (int t = 0; t < nt; ++t) {
     const int cur = t & 1;
     if (t + 1 < nt) {
-      sa.load(A, p.lda, bm0, (t + 1) * BK, p.M, p.K, tid);
-      sb.load(B, p.ldb, bn0, (t + 1) * BK, p.N, p.K, tid);
+      sa.load(A, p.lda, bm0, (kt0 + t + 1) * BK, p.M, p.K, tid);
+      sb.load(B, p.ldb, bn0, (kt0 + t + 1) * BK, p.N, p.K, tid);
     }
-    const char* la = smem + cur * STAGE + (wm + (lane & 15)) * ROWB;
-    const char* lb = smem + cur * STAGE + BM * ROWB + (wn + (lane & 15)) * ROWB;
+    const char* ta = smem + cur * STAGE;
+    const char* tb = ta + ABYTES;
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
       for (int ks = 0; ks < BK / 32; ++ks) {
         bf16x8 af[MI], bfr[NI];
-        const int koff = ks * 64 + (lane >> 4) * 16;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(la + i * 16 * ROWB + koff);
+        for (int i = 0; i < MI; ++i) af[i] = load_frag_bf16<BM, AK>(ta, wm + i * 16, ks, lane);
 #pragma unroll
-        for (int j = 0; j < NI; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(lb + j * 16 * ROWB + koff);
+        for (int j = 0; j < NI; ++j) bfr[j] = load_frag_bf16<BN, BKM>(tb, wn + j * 16, ks, lane);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-          for (int j = 0; j < NI; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NI; ++j) {
+            if constexpr (ATOMIC) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          }
       }
     } else {
+      const char* la = ta + (wm + (lane & 15)) * ROWB;
+      const char* lb = tb + (wn + (lane & 15)) * ROWB;
 #pragma unroll
       for (int ks = 0; ks < BK / 4; ++ks) {
         float af[MI], bfr[NI];
@@ -165,133 +236,166 @@ __device__ __forceinline__ void gemm_body(const GemmP& p) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-          for (int j = 0; j < NI; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NI; ++j) {
+            if constexpr (ATOMIC) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          }
       }
     }
     if (t + 1 < nt) {
       sa.store(smem + (cur ^ 1) * STAGE, tid);
-      sb.store(smem + (cur ^ 1) * STAGE + BM * ROWB, tid);
+      sb.store(smem + (cur ^ 1) * STAGE + ABYTES, tid);
     }
     __syncthreads();
   }
 
-  // ---- epilogue: lane owns m = ... + (lane&15), n = ... + (lane>>4)*4 + r ----
   float alpha = p.alpha;
   if (p.alpha_dev) alpha *= p.alpha_dev[0];
-  const DropCtx dc = make_drop(p.seed, p.tag, p.drop_p);
-  const bool vec_ok = ((p.ldc & 3) == 0) && ((p.N & 3) == 0) && (!p.residual || (p.ldr & 3) == 0) &&
-                      (!p.aux || (p.ldaux & 3) == 0);
+  if constexpr (ATOMIC) {
+    // lane owns n = ... + (lane&15), m = ... + (lane>>4)*4 + r
+    float* Cf = reinterpret_cast<float*>(p.C);
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int m = bm0 + wm + i * 16 + (lane & 15);
-    if (m >= p.M) continue;
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int n0 = bn0 + wn + j * 16 + (lane >> 4) * 4;
-      if (n0 >= p.N) continue;
-      float v[4];
+      for (int j = 0; j < NI; ++j) {
+        const int n = bn0 + wn + j * 16 + (lane & 15);
+        if (n >= p.N) continue;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * alpha;
-      const int nv = (p.N - n0) < 4 ? (p.N - n0) : 4;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (r >= nv) break;
-        const int n = n0 + r;
-        float x = v[r];
-        if (p.bias) x += p.bias[n];
-        if (p.act == KLAB_ACT_RELU) x = fmaxf(x, 0.f);
-        else if (p.act == KLAB_ACT_GELU) x = gelu_erf(x);
-        if (p.aux) {
-          float a = to_f32(reinterpret_cast<const T*>(p.aux)[(long)m * p.ldaux + n]);
-          if (p.aux_mode == KLAB_AUX_NONZERO) x = (a != 0.f) ? x * p.aux_scale : 0.f;
-          else if (p.aux_mode == KLAB_AUX_DGELU) x *= gelu_erf_grad(a);
+        for (int r = 0; r < 4; ++r) {
+          const int m = bm0 + wm + i * 16 + (lane >> 4) * 4 + r;
+          if (m < p.M) atomicAdd(Cf + (long)m * p.ldc + n, acc[i][j][r] * alpha);
         }
-        x *= drop_mult(dc, (uint64_t)m * (uint64_t)p.N + (uint64_t)n);
-        if (p.residual) {
-          x += p.r_f32 ? reinterpret_cast<const float*>(p.residual)[(long)m * p.ldr + n]
-                       : to_f32(reinterpret_cast<const T*>(p.residual)[(long)m * p.ldr + n]);
-        }
-        v[r] = x;
       }
-      if (p.c_f32) {
-        float* c = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n0;
-        if (p.accumulate) {
+  } else {
+    // ---- epilogue: lane owns m = ... + (lane&15), n = ... + (lane>>4)*4 + r ----
+    const DropCtx dc = make_drop(p.seed, p.tag, p.drop_p);
+    const bool vec_ok = ((p.ldc & 3) == 0) && ((p.N & 3) == 0) && (!p.residual || (p.ldr & 3) == 0) &&
+                        (!p.aux || (p.ldaux & 3) == 0);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) if (r < nv) v[r] += c[r];
-        }
-        if (vec_ok && nv == 4) *reinterpret_cast<f32x4*>(c) = f32x4{v[0], v[1], v[2], v[3]};
-        else { for (int r = 0; r < nv; ++r) c[r] = v[r]; }
-      } else {
-        T* c = reinterpret_cast<T*>(p.C) + (long)m * p.ldc + n0;
-        if (p.accumulate) {
+    for (int i = 0; i < MI; ++i) {
+      const int m = bm0 + wm + i * 16 + (lane & 15);
+      if (m >= p.M) continue;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) if (r < nv) v[r] += to_f32(c[r]);
+      for (int j = 0; j < NI; ++j) {
+        const int n0 = bn0 + wn + j * 16 + (lane >> 4) * 4;
+        if (n0 >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * alpha;
+        const int nv = (p.N - n0) < 4 ? (p.N - n0) : 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (r >= nv) break;
+          const int n = n0 + r;
+          float x = v[r];
+          if (p.bias) x += p.bias[n];
+          if (p.act == KLAB_ACT_RELU) x = fmaxf(x, 0.f);
+          else if (p.act == KLAB_ACT_GELU) x = gelu_erf(x);
+          if (p.aux) {
+            float a = to_f32(reinterpret_cast<const T*>(p.aux)[(long)m * p.ldaux + n]);
+            if (p.aux_mode == KLAB_AUX_NONZERO) x = (a != 0.f) ? x * p.aux_scale : 0.f;
+            else if (p.aux_mode == KLAB_AUX_DGELU) x *= gelu_erf_grad(a);
+          }
+          x *= drop_mult(dc, (uint64_t)m * (uint64_t)p.N + (uint64_t)n);
+          if (p.residual) {
+            x += p.r_f32 ? reinterpret_cast<const float*>(p.residual)[(long)m * p.ldr + n]
+                         : to_f32(reinterpret_cast<const T*>(p.residual)[(long)m * p.ldr + n]);
+          }
+          v[r] = x;
         }
-        if constexpr (sizeof(T) == 2) {
-          if (vec_ok && nv == 4) {
-            bf16x4 o = {from_f32<bf16_t>(v[0]), from_f32<bf16_t>(v[1]), from_f32<bf16_t>(v[2]), from_f32<bf16_t>(v[3])};
-            *reinterpret_cast<bf16x4*>(c) = o;
-          } else { for (int r = 0; r < nv; ++r) c[r] = from_f32<T>(v[r]); }
-        } else {
+        if (p.c_f32) {
+          float* c = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n0;
+          if (p.accumulate) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (r < nv) v[r] += c[r];
+          }
           if (vec_ok && nv == 4) *reinterpret_cast<f32x4*>(c) = f32x4{v[0], v[1], v[2], v[3]};
           else { for (int r = 0; r < nv; ++r) c[r] = v[r]; }
+        } else {
+          T* c = reinterpret_cast<T*>(p.C) + (long)m * p.ldc + n0;
+          if (p.accumulate) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (r < nv) v[r] += to_f32(c[r]);
+          }
+          if constexpr (sizeof(T) == 2) {
+            if (vec_ok && nv == 4) {
+              bf16x4 o = {from_f32<bf16_t>(v[0]), from_f32<bf16_t>(v[1]), from_f32<bf16_t>(v[2]), from_f32<bf16_t>(v[3])};
+              *reinterpret_cast<bf16x4*>(c) = o;
+            } else { for (int r = 0; r < nv; ++r) c[r] = from_f32<T>(v[r]); }
+          } else {
+            if (vec_ok && nv == 4) *reinterpret_cast<f32x4*>(c) = f32x4{v[0], v[1], v[2], v[3]};
+            else { for (int r = 0; r < nv; ++r) c[r] = v[r]; }
+          }
         }
       }
     }
   }
 }
 
-template <typename T, int BM, int BN, bool AK, bool BKM>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmP p) { gemm_body<T, BM, BN, AK, BKM>(p); }
+template <typename T, int BM, int BN, bool AK, bool BKM, bool ATOMIC>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmP p) { gemm_body<T, BM, BN, AK, BKM, ATOMIC>(p); }
+// the LM-head logits GEMM under its own symbol, so that profiles and the in-process probe
+// (klab_engine_probe_*) can be matched kernel for kernel
 template <typename T>
-__global__ __launch_bounds__(256) void klab_lmhead_gemm(GemmP p) { gemm_body<T, 128, 128, true, true>(p); }
+__global__ __launch_bounds__(256) void klab_lmhead_gemm(GemmP p) { gemm_body<T, 128, 128, true, true, false>(p); }
 
-template <typename T, int BM, int BN, bool AK, bool BKM>
-static int launch_gemm(const GemmP& p, hipStream_t s) {
-  const size_t lds = 2 * (size_t)(BM + BN) * ROWB;
-  static bool attr_set = false;
-  auto kern = gemm_kernel<T, BM, BN, AK, BKM>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
+template <typename K>
+static int launch_kernel(K kern, const GemmP& p, int BM, int BN, size_t lds, hipStream_t s) {
+  static std::mutex mu;
+  static std::map<const void*, size_t> attr;
+  {
+    std::lock_guard<std::mutex> g(mu);
+    const void* key = reinterpret_cast<const void*>(kern);
+    auto it = attr.find(key);
+    if (it == attr.end() || it->second < lds) {
+      hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      attr[key] = lds;
+    }
   }
-  const int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(tm * tn)), dim3(256), lds, s, p);
+  const long tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tm * tn * p.splits)), dim3(256), lds, s, p);
   KLAB_LAUNCH_CHECK();
   return KLAB_OK;
 }
 
-template <typename T>
-static int launch_lmhead(const GemmP& p, hipStream_t s) {
-  const size_t lds = 2 * (size_t)(128 + 128) * ROWB;
-  static bool attr_set = false;
-  auto kern = klab_lmhead_gemm<T>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
-  const int tm = (p.M + 127) / 128, tn = (p.N + 127) / 128;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(tm * tn)), dim3(256), lds, s, p);
-  KLAB_LAUNCH_CHECK();
-  return KLAB_OK;
+template <typename T, int BM, int BN, bool AK, bool BKM>
+static int launch_gemm(const GemmP& p, bool atomic, hipStream_t s) {
+  constexpr size_t lds = 2 * (size_t)(TileBytes<T, BM, AK>::value + TileBytes<T, BN, BKM>::value);
+  if (atomic) return launch_kernel(gemm_kernel<T, BM, BN, AK, BKM, true>, p, BM, BN, lds, s);
+  return launch_kernel(gemm_kernel<T, BM, BN, AK, BKM, false>, p, BM, BN, lds, s);
 }
 
 template <typename T, int BM, int BN>
-static int dispatch_layout(const GemmP& p, hipStream_t s) {
-  if (p.a_kmajor && p.b_kmajor) return launch_gemm<T, BM, BN, true, true>(p, s);
-  if (p.a_kmajor && !p.b_kmajor) return launch_gemm<T, BM, BN, true, false>(p, s);
-  if (!p.a_kmajor && p.b_kmajor) return launch_gemm<T, BM, BN, false, true>(p, s);
-  return launch_gemm<T, BM, BN, false, false>(p, s);
+static int dispatch_layout(const GemmP& p, bool atomic, hipStream_t s) {
+  if (p.a_kmajor && p.b_kmajor) return launch_gemm<T, BM, BN, true, true>(p, atomic, s);
+  if (p.a_kmajor && !p.b_kmajor) return launch_gemm<T, BM, BN, true, false>(p, atomic, s);
+  if (!p.a_kmajor && p.b_kmajor) return launch_gemm<T, BM, BN, false, true>(p, atomic, s);
+  return launch_gemm<T, BM, BN, false, false>(p, atomic, s);
 }
 
+// tile / split-K choice: the largest tile that still gives about one workgroup per CU; when even the
+// smallest does not and the caller allows atomic accumulation, split K until the chip is covered.
 template <typename T>
-static int dispatch_tile(const GemmP& p, hipStream_t s) {
-  const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-  if (t128 >= 256) return dispatch_layout<T, 128, 128>(p, s);
-  return dispatch_layout<T, 64, 64>(p, s);
+static int dispatch_tile(GemmP& p, bool atomic_ok, hipStream_t s) {
+  auto tiles = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+  const int BK = MmaTraits<T>::BK;
+  const int nt = (p.K + BK - 1) / BK;
+  p.splits = 1;
+  if (tiles(128, 128) >= 240) return dispatch_layout<T, 128, 128>(p, false, s);
+  if (tiles(128, 64) >= 240) return dispatch_layout<T, 128, 64>(p, false, s);
+  if (atomic_ok && nt >= 16) {
+    const bool big = p.M >= 128 && p.N >= 64;
+    const long t = big ? tiles(128, 64) : tiles(64, 64);
+    long sp = (256 + t - 1) / t;
+    if (sp > nt / 8) sp = nt / 8;   // at least 8 k-tiles (512 k) per split
+    if (sp > 16) sp = 16;
+    if (sp >= 2) {
+      p.splits = (int)sp;
+      return big ? dispatch_layout<T, 128, 64>(p, true, s) : dispatch_layout<T, 64, 64>(p, true, s);
+    }
+  }
+  return dispatch_layout<T, 64, 64>(p, false, s);
 }
 
 }  // namespace klab
@@ -306,6 +410,8 @@ extern "C" int klab_gemm(const klab_gemm_args* a, void* stream) {
   if (a->a_kmajor ? (a->K % vec) : (a->M % vec)) return KLAB_ERR_UNSUPPORTED;
   if (a->b_kmajor ? (a->K % vec) : (a->N % vec)) return KLAB_ERR_UNSUPPORTED;
   if (((uintptr_t)a->A & 15) || ((uintptr_t)a->B & 15) || ((uintptr_t)a->C & 15)) return KLAB_ERR_UNSUPPORTED;
+  if (a->dtype != KLAB_F32 && a->dtype != KLAB_BF16) return KLAB_ERR_BADARG;
+  if (a->c_dtype != KLAB_F32 && a->c_dtype != a->dtype) return KLAB_ERR_BADARG;
   GemmP p;
   p.M = a->M; p.N = a->N; p.K = a->K;
   p.A = a->A; p.lda = a->lda; p.a_kmajor = a->a_kmajor;
@@ -315,11 +421,15 @@ extern "C" int klab_gemm(const klab_gemm_args* a, void* stream) {
   p.aux = a->aux; p.ldaux = a->ldaux; p.aux_mode = a->aux_mode; p.aux_scale = a->aux_scale;
   p.residual = a->residual; p.ldr = a->ldr; p.r_f32 = (a->r_dtype == KLAB_F32);
   p.drop_p = a->drop_p; p.seed = a->seed_dev; p.tag = a->drop_tag;
-  if (a->dtype != KLAB_F32 && a->dtype != KLAB_BF16) return KLAB_ERR_BADARG;
-  if (a->c_dtype != KLAB_F32 && a->c_dtype != a->dtype) return KLAB_ERR_BADARG;
+  p.splits = 1;
   hipStream_t s = (hipStream_t)stream;
-  if (a->name_tag == 1 && a->a_kmajor && a->b_kmajor)
-    return a->dtype == KLAB_BF16 ? launch_lmhead<bf16_t>(p, s) : launch_lmhead<float>(p, s);
-  if (a->dtype == KLAB_BF16) return dispatch_tile<bf16_t>(p, s);
-  return dispatch_tile<float>(p, s);
+  if (a->name_tag == 1 && a->a_kmajor && a->b_kmajor) {
+    const size_t lds = 2 * (size_t)(128 + 128) * ROWB;
+    if (a->dtype == KLAB_BF16) return launch_kernel(klab_lmhead_gemm<bf16_t>, p, 128, 128, lds, s);
+    return launch_kernel(klab_lmhead_gemm<float>, p, 128, 128, lds, s);
+  }
+  // split-K with float atomics only for a plain accumulating f32 product (the wgrad form)
+  const bool atomic_ok = a->atomic_ok && p.c_f32 && a->accumulate && !a->bias && !a->act && !a->aux && !a->residual && a->drop_p == 0.f;
+  if (a->dtype == KLAB_BF16) return dispatch_tile<bf16_t>(p, atomic_ok, s);
+  return dispatch_tile<float>(p, atomic_ok, s);
 }

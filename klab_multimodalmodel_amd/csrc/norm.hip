@@ -71,20 +71,17 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
 //   dxt    = T(dx * dropmult_prev)      (grad of the previous sub-layer's GEMM output, ready as a
 //                                        bf16 GEMM operand: the residual add + dropout of HF/t5:400,141)
 // ------------------------------------------------------------------------------------------
-template <typename TY, int MAXC>
+template <typename TY>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                           const float* __restrict__ w, const float* __restrict__ rstd,
                                                           const float* __restrict__ dres, float* __restrict__ dx,
-                                                          TY* __restrict__ dxt, float* __restrict__ dw, int rows, int d,
+                                                          TY* __restrict__ dxt, int rows, int d,
                                                           int grp, int grp_stride, int off, float p_y, uint32_t tag_y,
                                                           float p_prev, uint32_t tag_prev, const uint32_t* seed) {
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
   const DropCtx dcy = make_drop(seed, tag_y, p_y);
   const DropCtx dcp = make_drop(seed, tag_prev, p_prev);
-  float dwacc[MAXC][4];
-#pragma unroll
-  for (int i = 0; i < MAXC; ++i) dwacc[i][0] = dwacc[i][1] = dwacc[i][2] = dwacc[i][3] = 0.f;
   for (long row = (long)blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * wpb) {
     const float* xr = x + row * d;
     const long yrow = remap_row(row, grp, grp_stride, off);  // dy lives in the remapped space
@@ -100,10 +97,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
     }
     dot = wave_sum(dot);
     const float k = dot * r * r * r / (float)d;
-#pragma unroll
-    for (int ci = 0; ci < MAXC; ++ci) {  // compile-time ci keeps dwacc in registers
-      const int c = lane * 4 + ci * 256;
-      if (c >= d) continue;
+    for (int c = lane * 4; c < d; c += 256) {
       f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
       f32x4 g = *reinterpret_cast<const f32x4*>(w + c);
       f32x4 e = *reinterpret_cast<const f32x4*>(dyr + c);
@@ -112,7 +106,6 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
       for (int i = 0; i < 4; ++i) {
         const float de = e[i] * drop_mult(dcy, (uint64_t)yrow * d + c + i);
         o[i] = r * g[i] * de - v[i] * k;
-        dwacc[ci][i] += de * v[i] * r;
       }
       if (dres) {
         f32x4 q = *reinterpret_cast<const f32x4*>(dres + row * d + c);
@@ -127,15 +120,28 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
       }
     }
   }
-  if (dw) {
-#pragma unroll
-    for (int ci = 0; ci < MAXC; ++ci) {
-      const int c = lane * 4 + ci * 256;
-      if (c >= d) continue;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) atomicAdd(dw + c + i, dwacc[ci][i]);
+}
+
+// dw[c] += sum_rows dy_eff[row,c] * x[row,c] * rstd[row]: a column reduction, kept out of the row kernel
+// (per-wave register partials + 512-way same-address atomics made that kernel 10x slower than its bytes).
+// Block = 64 columns x 4 row lanes over a slab of rows; one 256-B atomic wave-instruction per block.
+__global__ __launch_bounds__(256) void rmsnorm_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ rstd,
+                                                         float* __restrict__ dw, int rows, int d, int grp, int grp_stride, int off, float p_y,
+                                                         uint32_t tag_y, const uint32_t* seed) {
+  __shared__ float red[4][64];
+  const DropCtx dcy = make_drop(seed, tag_y, p_y);
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  float a = 0.f;
+  if (col < d) {
+    for (long row = (long)blockIdx.y * 4 + rl; row < rows; row += (long)gridDim.y * 4) {
+      const long yrow = remap_row(row, grp, grp_stride, off);
+      a += dy[yrow * d + col] * drop_mult(dcy, (uint64_t)yrow * d + col) * x[row * d + col] * rstd[row];
     }
   }
+  red[rl][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (rl == 0 && col < d) atomicAdd(dw + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -190,21 +196,15 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const TI* __restrict
 // LayerNorm backward: given dout (grad of `out`, in the remapped row space, with the same output
 // dropout), y, mean, rstd:  dy = LN'(dout) as T (GEMM operand), dgamma/dbeta via f32 atomics.
 // The shortcut gradient is dout itself (caller keeps using it as the residual-stream gradient).
-template <typename TI, int MAXC>
+template <typename TI>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dout, const TI* __restrict__ y,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                            const float* __restrict__ rstd, TI* __restrict__ dy,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int C,
+                                                            const float* __restrict__ rstd, TI* __restrict__ dy, int rows, int C,
                                                             int grp, int grp_stride, int off, float p, const uint32_t* seed,
                                                             uint32_t tag) {
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
   const DropCtx dc = make_drop(seed, tag, p);
-  float dg[MAXC][4], db[MAXC][4];
-#pragma unroll
-  for (int i = 0; i < MAXC; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) dg[i][j] = db[i][j] = 0.f;
   for (long row = (long)blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * wpb) {
     const TI* yr = y + row * C;
     const long orow = remap_row(row, grp, grp_stride, off);
@@ -225,10 +225,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
     s1 = wave_sum(s1) / (float)C;
     s2 = wave_sum(s2) / (float)C;
-#pragma unroll
-    for (int ci = 0; ci < MAXC; ++ci) {
-      const int c = lane * 4 + ci * 256;
-      if (c >= C) continue;
+    for (int c = lane * 4; c < C; c += 256) {
       f32x4 v = load4<TI>(yr + c);
       f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
       f32x4 e = *reinterpret_cast<const f32x4*>(dor + c);
@@ -238,20 +235,36 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         const float de = e[i] * drop_mult(dc, (uint64_t)orow * C + c + i);
         const float xh = (v[i] - mu) * r;
         o[i] = r * (g[i] * de - s1 - xh * s2);
-        dg[ci][i] += de * xh; db[ci][i] += de;
       }
       if (dy) store4<TI>(dy + row * C + c, o[0], o[1], o[2], o[3]);
     }
   }
-#pragma unroll
-  for (int ci = 0; ci < MAXC; ++ci) {
-    const int c = lane * 4 + ci * 256;
-    if (c >= C) continue;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (dgamma) atomicAdd(dgamma + c + i, dg[ci][i]);
-      if (dbeta) atomicAdd(dbeta + c + i, db[ci][i]);
+}
+
+template <typename TI>
+__global__ __launch_bounds__(256) void layernorm_dgb_kernel(const float* __restrict__ dout, const TI* __restrict__ y, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int rows, int C, int grp, int grp_stride, int off, float p, const uint32_t* seed,
+                                                            uint32_t tag) {
+  __shared__ float rg[4][64], rb[4][64];
+  const DropCtx dc = make_drop(seed, tag, p);
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  float ag = 0.f, ab = 0.f;
+  if (col < C) {
+    for (long row = (long)blockIdx.y * 4 + rl; row < rows; row += (long)gridDim.y * 4) {
+      const long orow = remap_row(row, grp, grp_stride, off);
+      const float de = dout[orow * C + col] * drop_mult(dc, (uint64_t)orow * C + col);
+      ag += de * (to_f32(y[row * C + col]) - mean[row]) * rstd[row];
+      ab += de;
     }
+  }
+  rg[rl][threadIdx.x & 63] = ag; rb[rl][threadIdx.x & 63] = ab;
+  __syncthreads();
+  if (rl == 0 && col < C) {
+    const int t = threadIdx.x;
+    if (dgamma) atomicAdd(dgamma + col, rg[0][t] + rg[1][t] + rg[2][t] + rg[3][t]);
+    if (dbeta) atomicAdd(dbeta + col, rb[0][t] + rb[1][t] + rb[2][t] + rb[3][t]);
   }
 }
 
@@ -285,19 +298,23 @@ extern "C" int klab_rmsnorm_bwd(const float* dy, const float* x, const float* w,
                                 int off, float p_y, uint32_t tag_y, float p_prev, uint32_t tag_prev,
                                 const uint32_t* seed_dev, void* stream) {
   if (!dy || !x || !w || !rstd || rows < 0 || d <= 0 || (d & 3)) return KLAB_ERR_BADARG;
-  if (d > 256 * 8) return KLAB_ERR_UNSUPPORTED;  // per-lane dw partials cover d <= 2048
   if (rows == 0) return KLAB_OK;
   hipStream_t s = (hipStream_t)stream;
-  // fewer, fatter waves: each wave keeps dw partials in registers across its rows
-  int g = (rows + 31) / 32;
-  g = g < 1 ? 1 : (g > 512 ? 512 : g);
+  const int g = norm_grid(rows);
   if (dxt_dtype == KLAB_BF16)
-    hipLaunchKernelGGL((rmsnorm_bwd_kernel<bf16_t, 8>), dim3(g), dim3(256), 0, s, dy, x, w, rstd, dres, dx, (bf16_t*)dxt, dw, rows,
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, s, dy, x, w, rstd, dres, dx, (bf16_t*)dxt, rows,
                        d, grp, grp_stride, off, p_y, tag_y, p_prev, tag_prev, seed_dev);
   else
-    hipLaunchKernelGGL((rmsnorm_bwd_kernel<float, 8>), dim3(g), dim3(256), 0, s, dy, x, w, rstd, dres, dx, (float*)dxt, dw, rows, d,
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel<float>, dim3(g), dim3(256), 0, s, dy, x, w, rstd, dres, dx, (float*)dxt, rows, d,
                        grp, grp_stride, off, p_y, tag_y, p_prev, tag_prev, seed_dev);
   KLAB_LAUNCH_CHECK();
+  if (dw) {
+    int gy = (rows + 63) / 64;
+    gy = gy < 1 ? 1 : (gy > 64 ? 64 : gy);
+    hipLaunchKernelGGL(rmsnorm_dw_kernel, dim3((d + 63) / 64, gy), dim3(256), 0, s, dy, x, rstd, dw, rows, d, grp, grp_stride, off, p_y, tag_y,
+                       seed_dev);
+    KLAB_LAUNCH_CHECK();
+  }
   return KLAB_OK;
 }
 
@@ -326,17 +343,23 @@ extern "C" int klab_layernorm_bwd(const float* dout, const void* y, int y_dtype,
                                   int grp_stride, int off, float drop_p, const uint32_t* seed_dev, uint32_t tag,
                                   void* stream) {
   if (!dout || !y || !gamma || !mean || !rstd || rows < 0 || C <= 0 || (C & 3)) return KLAB_ERR_BADARG;
-  if (C > 256 * 8) return KLAB_ERR_UNSUPPORTED;
   if (rows == 0) return KLAB_OK;
   hipStream_t s = (hipStream_t)stream;
-  int g = (rows + 31) / 32;
-  g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
-  if (y_dtype == KLAB_BF16)
-    hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, 8>), dim3(g), dim3(256), 0, s, dout, (const bf16_t*)y, gamma, mean, rstd,
-                       (bf16_t*)dy, dgamma, dbeta, rows, C, grp, grp_stride, off, drop_p, seed_dev, tag);
-  else
-    hipLaunchKernelGGL((layernorm_bwd_kernel<float, 8>), dim3(g), dim3(256), 0, s, dout, (const float*)y, gamma, mean, rstd,
-                       (float*)dy, dgamma, dbeta, rows, C, grp, grp_stride, off, drop_p, seed_dev, tag);
+  const int g = norm_grid(rows);
+  int gy = (rows + 63) / 64;
+  gy = gy < 1 ? 1 : (gy > 128 ? 128 : gy);
+  const dim3 g2((C + 63) / 64, gy);
+  if (y_dtype == KLAB_BF16) {
+    if (dy) hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, s, dout, (const bf16_t*)y, gamma, mean, rstd,
+                               (bf16_t*)dy, rows, C, grp, grp_stride, off, drop_p, seed_dev, tag);
+    if (dgamma || dbeta) hipLaunchKernelGGL(layernorm_dgb_kernel<bf16_t>, g2, dim3(256), 0, s, dout, (const bf16_t*)y, mean, rstd, dgamma,
+                                            dbeta, rows, C, grp, grp_stride, off, drop_p, seed_dev, tag);
+  } else {
+    if (dy) hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(g), dim3(256), 0, s, dout, (const float*)y, gamma, mean, rstd,
+                               (float*)dy, rows, C, grp, grp_stride, off, drop_p, seed_dev, tag);
+    if (dgamma || dbeta) hipLaunchKernelGGL(layernorm_dgb_kernel<float>, g2, dim3(256), 0, s, dout, (const float*)y, mean, rstd, dgamma,
+                                            dbeta, rows, C, grp, grp_stride, off, drop_p, seed_dev, tag);
+  }
   KLAB_LAUNCH_CHECK();
   return KLAB_OK;
 }

@@ -16,9 +16,10 @@ def _seed_ptr(seed):
 
 def gemm(A, B, C_out, *, M, N, K, a_kmajor=True, b_kmajor=True, lda=None, ldb=None, ldc=None, alpha=1.0,
          alpha_dev=None, bias=None, act=L.ACT_NONE, aux=None, aux_mode=L.AUX_NONE, aux_scale=1.0, residual=None,
-         drop_p=0.0, seed=None, tag=0, accumulate=False):
+         drop_p=0.0, seed=None, tag=0, accumulate=False, atomic_ok=False, name_tag=0):
     lib = L.load()
     a = L.GemmArgs()
+    a.atomic_ok, a.name_tag = int(atomic_ok), name_tag
     a.M, a.N, a.K = M, N, K
     a.dtype = L.dtype_code(A.dtype)
     assert B.dtype == A.dtype

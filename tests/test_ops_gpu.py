@@ -96,6 +96,27 @@ def test_gemm_wgrad_ragged_contraction(ops, dt):
 
 
 @pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,N,K", [(512, 512, 4096), (128, 64, 3712), (64, 64, 2048), (1536, 512, 4096)])
+def test_gemm_wgrad_split_k_atomics(ops, dt, M, N, K):
+    # small outputs + long contraction: the kernel splits K over workgroups and adds partials with f32 atomics
+    dY, X = rnd(K, M, seed=7).to(dt), rnd(K, N, seed=8).to(dt)
+    C2 = torch.full((M, N), 0.5, device="cuda")
+    ops.gemm(dev(dY), dev(X), C2, M=M, N=N, K=K, a_kmajor=False, b_kmajor=False, accumulate=True, atomic_ok=True)
+    assert rel_l2(C2.cpu(), dY.float().t() @ X.float() + 0.5) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_lmhead_symbol_matches_generic_gemm(ops, dt):
+    M, N, K = 256, 1024, 128
+    A, B = rnd(M, K, seed=1).to(dt), rnd(N, K, seed=2).to(dt)
+    C1 = torch.empty(M, N, device="cuda", dtype=dt)
+    C2 = torch.empty(M, N, device="cuda", dtype=dt)
+    ops.gemm(dev(A), dev(B), C1, M=M, N=N, K=K, alpha=0.25)
+    ops.gemm(dev(A), dev(B), C2, M=M, N=N, K=K, alpha=0.25, name_tag=1)
+    assert torch.equal(C1, C2)
+
+
+@pytest.mark.parametrize("dt", DT)
 def test_gemm_aux_modes_and_alpha_dev(ops, dt):
     M, N, K = 72, 48, 32
     A, B = rnd(M, K, seed=1).to(dt), rnd(N, K, seed=2).to(dt)
