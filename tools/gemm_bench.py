@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Per-shape timing of klab_gemm on the shapes of BASELINE configs[1] (B=64): TFLOP/s per launch."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from klab_multimodalmodel_amd import ops  # noqa: E402
+
+SHAPES = [  # name, M, N, K, a_kmajor, b_kmajor, atomic
+    ("lmhead fwd", 4096, 32128, 512, True, True, False),
+    ("lmhead dgrad", 4096, 512, 32128, True, False, False),
+    ("lmhead wgrad", 32128, 512, 4096, False, False, True),
+    ("qkv fwd", 4096, 1536, 512, True, True, False),
+    ("o fwd", 4096, 512, 512, True, True, False),
+    ("wi fwd", 4096, 2048, 512, True, True, False),
+    ("wo fwd", 4096, 512, 2048, True, True, False),
+    ("kv_all fwd", 3712, 6144, 512, True, True, False),
+    ("qkv dgrad", 4096, 512, 1536, True, False, False),
+    ("wi dgrad", 4096, 512, 2048, True, False, False),
+    ("wo dgrad", 4096, 2048, 512, True, False, False),
+    ("o wgrad", 512, 512, 4096, False, False, True),
+    ("qkv wgrad", 1536, 512, 4096, False, False, True),
+    ("wi wgrad", 2048, 512, 4096, False, False, True),
+    ("wo wgrad", 512, 2048, 4096, False, False, True),
+    ("swin0 qkv", 200704, 192, 64, True, True, False),
+    ("swin0 proj", 200704, 64, 64, True, True, False),
+    ("swin0 fc1", 200704, 256, 64, True, True, False),
+    ("swin0 fc2", 200704, 64, 256, True, True, False),
+    ("swin2 qkv", 12544, 768, 256, True, True, False),
+    ("swin2 fc1", 12544, 1024, 256, True, True, False),
+    ("swin2 fc2", 12544, 256, 1024, True, True, False),
+]
+
+
+def main():
+    dt = torch.bfloat16
+    tot = 0.0
+    for name, M, N, K, ak, bk, atomic in SHAPES:
+        A = torch.randn((M, K) if ak else (K, M), device="cuda").to(dt)
+        B = torch.randn((N, K) if bk else (K, N), device="cuda").to(dt)
+        C = torch.zeros(M, N, device="cuda", dtype=torch.float32 if atomic else dt)
+        kw = dict(M=M, N=N, K=K, a_kmajor=ak, b_kmajor=bk, accumulate=atomic, atomic_ok=atomic)
+        for _ in range(3):
+            ops.gemm(A, B, C, **kw)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 20
+        e0.record()
+        for _ in range(n):
+            ops.gemm(A, B, C, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / n * 1e3
+        tf = 2.0 * M * N * K / (us * 1e-6) / 1e12
+        tot += us
+        print(f"{name:14s} M={M:6d} N={N:6d} K={K:6d}  {us:9.1f} us  {tf:8.1f} TF/s")
+    print("sum us", tot)
+
+
+if __name__ == "__main__":
+    main()
