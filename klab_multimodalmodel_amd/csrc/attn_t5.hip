@@ -251,6 +251,10 @@ static int set_lds(K kern, size_t bytes) {
 
 }  // namespace klab
 
+namespace klab {
+int t5_attn_fwd_mfma_dispatch(const klab_attn_args* a, hipStream_t s);  // attn_t5_mfma.hip
+int t5_attn_bwd_mfma_dispatch(const klab_attn_args* a, hipStream_t s);
+}
 using namespace klab;
 
 static int check_attn(const klab_attn_args* a) {
@@ -276,6 +280,10 @@ extern "C" int klab_t5_attn_fwd(const klab_attn_args* a, void* stream) {
   int rc = check_attn(a);
   if (rc) return rc;
   if (a->B <= 0 || a->Lq <= 0 || a->Lk <= 0) return KLAB_OK;
+  if (a->dtype == KLAB_BF16) {  // matrix-core path first; fall through to the generic kernel outside its envelope
+    rc = t5_attn_fwd_mfma_dispatch(a, (hipStream_t)stream);
+    if (rc != KLAB_ERR_UNSUPPORTED) return rc;
+  }
   const size_t es = a->dtype == KLAB_BF16 ? 2 : 4;
   const int vec = a->dtype == KLAB_BF16 ? 8 : 4;
   const size_t lds = 2 * (size_t)a->Lk * (a->dk + vec) * es + (size_t)TQ * a->dk * 4 + (size_t)TQ * (a->Lk + 1) * 4;
@@ -298,6 +306,10 @@ extern "C" int klab_t5_attn_bwd(const klab_attn_args* a, void* stream) {
   if (rc) return rc;
   if (!a->dctx || !a->dq || !a->dk_out || !a->dv || !a->lse) return KLAB_ERR_BADARG;
   if (a->B <= 0 || a->Lq <= 0 || a->Lk <= 0) return KLAB_OK;
+  if (a->dtype == KLAB_BF16) {
+    rc = t5_attn_bwd_mfma_dispatch(a, (hipStream_t)stream);
+    if (rc != KLAB_ERR_UNSUPPORTED) return rc;
+  }
   const size_t es = a->dtype == KLAB_BF16 ? 2 : 4;
   const int vec = a->dtype == KLAB_BF16 ? 8 : 4;
   const size_t lds = 2 * (size_t)a->Lk * (a->dk + vec) * es + 2 * (size_t)a->Lk * a->dk * 4 + 2 * (size_t)TQ * a->dk * 4 +
