@@ -113,25 +113,55 @@ class _LossFn(torch.autograd.Function):
         g = gout.detach().to(torch.float32).contiguous().view(1)
         direct = model._direct_grads
         targets = model._grad_targets()
-        accumulate = direct and any(p.grad is not None for p, _ in targets)
-        saved = None
-        if accumulate:  # .grad aliases the flat buffers the engine is about to overwrite: keep the running sums
-            saved = {m: model._flat[m].clone() for m in ("main", "swin") if model._flat.get(m) is not None}
         nseg = 3 if model.args.image_model_train else 2
-        for seg in range(nseg):
-            eng.backward(seg, g)
-            if model._segment_hook is not None and not accumulate:
-                model._segment_hook(seg)
-        if accumulate:
-            for m, t in saved.items():
-                model._flat[m].add_(t)
-            if model._segment_hook is not None:
-                for seg in range(nseg):
+        if not direct:
+            for seg in range(nseg):
+                eng.backward(seg, g)
+                if model._segment_hook is not None:
                     model._segment_hook(seg)
-        if direct:
-            if not accumulate:
-                for p, view in targets:
-                    p.grad = view
+        else:
+            # .grad tensors alias the flat buffers the engine is about to overwrite.  Per flat buffer: parameters whose
+            # .grad is None get fresh gradients; parameters that still hold a gradient (accumulation steps, or the Swin
+            # gradients the reference never zeroes) keep the running sum.
+            state, held = {}, {}
+            for mname in ("main", "swin"):
+                ps = [p for p, _v, mn in model._views if mn == mname and p.requires_grad]
+                if model._flat.get(mname) is None or not ps:
+                    continue
+                n_set = sum(p.grad is not None for p in ps)
+                state[mname] = "fresh" if n_set == 0 else ("all" if n_set == len(ps) else "mixed")
+                if n_set:
+                    held[mname] = model._flat[mname].clone()
+            seg_model = ("main", "main", "swin")
+
+            def settle(mname):
+                st = state.get(mname)
+                if st == "all":
+                    model._flat[mname].add_(held[mname])  # every .grad aliases the flat buffer: one fused add
+                elif st is not None:
+                    for p, view, mn in model._views:
+                        if mn != mname or not p.requires_grad:
+                            continue
+                        if p.grad is None:
+                            p.grad = view
+                        elif st == "mixed":
+                            off = view.storage_offset()
+                            view.add_(held[mname][off:off + view.numel()].view(view.shape))
+
+            for seg in range(nseg):
+                eng.backward(seg, g)
+                last_of_model = seg == nseg - 1 or seg_model[seg + 1] != seg_model[seg]
+                if state.get(seg_model[seg]) == "fresh":
+                    if model._segment_hook is not None:
+                        model._segment_hook(seg)
+                    if last_of_model:
+                        settle(seg_model[seg])
+                elif last_of_model:
+                    settle(seg_model[seg])
+                    if model._segment_hook is not None:
+                        for s2 in range(nseg):
+                            if seg_model[s2] == seg_model[seg]:
+                                model._segment_hook(s2)
             return (None,) * (5 + ctx.nparams)
         grads = []
         views = {id(p): v for p, v in targets}
@@ -250,9 +280,9 @@ class MyModel(nn.Module):
                     continue
                 for spec, p in zip(self._engine.params[mname], tree.ordered()):
                     if spec.grad_off >= 0:
-                        out.append((p, flat[spec.grad_off:spec.grad_off + p.numel()].view(p.shape)))
+                        out.append((p, flat[spec.grad_off:spec.grad_off + p.numel()].view(p.shape), mname))
             self._views = out
-        return [(p, v) for p, v in self._views if p.requires_grad]
+        return [(p, v) for p, v, _m in self._views if p.requires_grad]
 
     def flat_grads(self, model="main"):
         return self._flat.get(model)

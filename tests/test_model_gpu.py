@@ -172,3 +172,71 @@ def test_full_size_architecture_matches_oracle(dtype, loss_tol, cos_min):
     c = cosine(torch.cat(a), torch.cat(b))
     print("full-size", dtype, "loss", loss.item(), float(ref), "grad cosine", c, "rel-L2", rel_l2(torch.cat(a), torch.cat(b)))
     assert c > cos_min
+
+
+def _train_steps(wrap, accumulate=1, steps=3):
+    """the reference's loop body (ref/train.py:58-71) on a tiny config; returns losses and final weights."""
+    import torch.distributed as dist
+    m, g = build("tiny_b", torch.float32, True)
+    m.transformer.eval()  # deterministic (no dropout) so that the three gradient paths can be compared exactly
+    if wrap == "torch":
+        model = torch.nn.parallel.DistributedDataParallel(m, device_ids=[0])
+        core = model.module
+    elif wrap == "klab":
+        from klab_multimodalmodel_amd.ddp import DistributedDataParallel
+        model = DistributedDataParallel(m, device_ids=[0])
+        core = model.module
+    else:
+        model = core = m
+    opt = torch.optim.Adam(core.transformer.parameters(), lr=1e-3)
+    losses = []
+    for i in range(steps * accumulate):
+        loss = run(model, g) if wrap else run(m, g)
+        losses.append(loss.item())
+        (loss / accumulate).backward()
+        if (i + 1) % accumulate == 0:
+            opt.step()
+            opt.zero_grad()
+    w = {k: v.detach().clone() for k, v in core.transformer.state_dict().items()}
+    sg = core.image_model.get_parameter("layernorm.weight").grad
+    return losses, w, None if sg is None else sg.detach().clone()
+
+
+def test_reference_training_loop_under_stock_ddp_and_klab_ddp():
+    """`DDP(model)`, Adam over transformer.parameters(), accumulation, zero_grad -- ref/train.py:26-28,58-71.
+    Stock torch DDP (autograd-hook path), klab DDP (direct flat-gradient path) and no wrapper must agree."""
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        for acc in (1, 2):
+            l0, w0, s0 = _train_steps(None, acc)
+            l1, w1, s1 = _train_steps("torch", acc)
+            l2, w2, s2 = _train_steps("klab", acc)
+            assert l0[0] > l0[-1]  # it learns the batch
+            for a, b in ((l0, l1), (l0, l2)):
+                assert max(abs(x - y) for x, y in zip(a, b)) < 2e-4, (acc, a, b)
+            for k in w0:
+                assert rel_l2(w1[k].cpu(), w0[k].cpu()) < 2e-3, k  # Adam normalises: last-bit gradient differences (atomics) grow
+                assert rel_l2(w2[k].cpu(), w0[k].cpu()) < 2e-3, k
+            # Swin gradients are computed and accumulate forever (never zeroed by the optimizer: SURVEY §0.4)
+            assert s0 is not None and s1 is not None and s2 is not None
+            assert rel_l2(s1.cpu(), s0.cpu()) < 1e-3 and rel_l2(s2.cpu(), s0.cpu()) < 1e-3
+    finally:
+        dist.destroy_process_group()
+
+
+def test_generate_greedy_matches_oracle_argmax():
+    m, g = build("tiny_b", torch.float32, False)
+    inp = g["inputs"]
+    out = m({"pixel_values": inp["pixel_values"].cuda()}, {"input_ids": inp["src_ids"].cuda()}, return_loss=False)
+    assert out.shape[0] == inp["src_ids"].shape[0] and out.shape[1] <= 20 and int(out[0, 0]) == 0
+    # first generated token == argmax of the oracle's logits at decoder position 0
+    from oracle import swin_t5_oracle as O
+    sds = g["sds"]
+    tgt = torch.zeros(inp["src_ids"].shape[0], 1, dtype=torch.long)
+    _, parts = O.mymodel_forward(sds["swin"], sds["lang"], sds["main"], g["swin_cfg"], g["t5_cfg"], g["t5_cfg"], inp["pixel_values"],
+                                 inp["src_ids"], tgt, return_parts=True)
+    assert torch.equal(out[:, 1].cpu(), parts["logits"][:, 0].argmax(-1))
