@@ -388,15 +388,23 @@ struct GldsOperand {
       const int fr = lane & 15, fc = lane >> 4;
       return *reinterpret_cast<const bf16x8*>(stage + (r0 + fr) * 64 + ((fc ^ (((fr >> 2) & 1) << 1)) * 16));
     } else {
-      typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+      // inline asm, not the builtin: hipcc puts s_waitcnt vmcnt(0) in front of the ds_read_tr builtin whenever an
+      // LDS-DMA is in flight (it cannot tell the ring slots apart), which drained the 3-deep prefetch every k-tile.
+      // The caller issues `s_waitcnt lgkmcnt(0)` + sched_barrier before the first MFMA (frag_wait()).
+      typedef __attribute__((address_space(3))) char lds_char;
+      typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
       const int g = lane >> 4, q4 = (lane & 15) >> 2, pp = lane & 3;
       const int kr0 = 8 * g + q4, kr1 = kr0 + 4;
       const int chunk = (r0 >> 3) + (pp >> 1);
       const char* a0 = stage + kr0 * (ROWS * 2) + ((chunk ^ (mmajor_f<ROWS>(kr0) << 1)) * 16) + (pp & 1) * 8;
       const char* a1 = stage + kr1 * (ROWS * 2) + ((chunk ^ (mmajor_f<ROWS>(kr1) << 1)) * 16) + (pp & 1) * 8;
-      bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a0);
-      bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a1);
-      return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      const unsigned o0 = (unsigned)(uintptr_t)(lds_char*)a0, o1 = (unsigned)(uintptr_t)(lds_char*)a1;
+      u32x2 lo, hi;
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(o0) : "memory");
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(o1) : "memory");
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+      const u32x4 both = {lo[0], lo[1], hi[0], hi[1]};
+      return __builtin_bit_cast(bf16x8, both);
     }
   }
 };
@@ -469,6 +477,10 @@ __device__ __forceinline__ void gemm_glds_body(const GemmP& p) {
       for (int i = 0; i < MI; ++i) af[i] = OA::frag(ta, wm + i * 16, lane);
 #pragma unroll
       for (int j = 0; j < NI; ++j) bfr[j] = OB::frag(tb, wn + j * 16, lane);
+      if constexpr (!AK || !BKM) {  // asm transposed reads are invisible to the compiler's lgkmcnt bookkeeping
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     if (do_mma) {
 #pragma unroll
