@@ -112,6 +112,8 @@ typedef struct klab_attn_args {
   void* dk_out; long lddk;
   void* dv; long lddv;
   float* dbias;
+  void* ds_ws; /* optional scratch [B,H,Lq,roundup(Lk,32)] in `dtype`: with it the position-bias gradient is a
+                  deterministic batch reduction of stored dS instead of 64-way contended float atomics */
 } klab_attn_args;
 int klab_t5_attn_fwd(const klab_attn_args* a, void* stream);
 int klab_t5_attn_bwd(const klab_attn_args* a, void* stream);

@@ -33,7 +33,7 @@ class AttnArgs(C.Structure):
                 ("B", i32), ("H", i32), ("Lq", i32), ("Lk", i32), ("dk", i32),
                 ("drop_p", f32), ("seed_dev", vp), ("drop_tag", u32),
                 ("dctx", vp), ("lddo", i64), ("dq", vp), ("lddq", i64), ("dk_out", vp), ("lddk", i64),
-                ("dv", vp), ("lddv", i64), ("dbias", vp)]
+                ("dv", vp), ("lddv", i64), ("dbias", vp), ("ds_ws", vp)]
 
 
 class SwinAttnArgs(C.Structure):

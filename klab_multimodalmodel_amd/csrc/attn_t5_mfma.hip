@@ -34,6 +34,7 @@ struct AttnMP {
   bf16_t* dkk; long lddk;
   bf16_t* dv; long lddv;
   float* dbias;
+  bf16_t* ds_ws;
 };
 
 template <int COLS> struct TrImg {  // rows = contraction index, columns = COLS 16-bit elements
@@ -229,7 +230,8 @@ __global__ __launch_bounds__(256) void t5_attn_bwd_mfma(AttnMP p) {
     const int q = qt * 16 + (lane & 15);
     const float lq = lses[q], dq_ = delta[q];
     const float* brow = (p.bias && q < Lq) ? p.bias + ((long)h * Lq + q) * Lk : nullptr;
-    float* dbrow = (p.dbias && q < Lq) ? p.dbias + ((long)h * Lq + q) * Lk : nullptr;
+    float* dbrow = (p.dbias && !p.ds_ws && q < Lq) ? p.dbias + ((long)h * Lq + q) * Lk : nullptr;
+    bf16_t* dsrow = (p.ds_ws && q < Lq) ? p.ds_ws + (((long)b * p.H + h) * Lq + q) * Lkp : nullptr;
     bf16x8 qf[KS], dof[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) { qf[ks] = row_frag(Qr, KPITCH, qt * 16, ks, lane); dof[ks] = row_frag(dOr, KPITCH, qt * 16, ks, lane); }
@@ -262,6 +264,10 @@ __global__ __launch_bounds__(256) void t5_attn_bwd_mfma(AttnMP p) {
         }
       }
       const bf16x8 dsf = pack8(ds2[0], ds2[1]);
+      if (dsrow) {  // dS tile pair for the batch reduction (keys 32 s + 4 g .. and + 16)
+        *reinterpret_cast<bf16x4*>(dsrow + sidx * 32 + g * 4) = bf16x4{dsf[0], dsf[1], dsf[2], dsf[3]};
+        *reinterpret_cast<bf16x4*>(dsrow + sidx * 32 + 16 + g * 4) = bf16x4{dsf[4], dsf[5], dsf[6], dsf[7]};
+      }
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DKP>(Kt, sidx * 32, dt * 16, lane), dsf, acc[dt], 0, 0, 0);
     }
@@ -333,6 +339,17 @@ __global__ __launch_bounds__(256) void t5_attn_bwd_mfma(AttnMP p) {
   }
 }
 
+// dbias[h,q,k] += sum_b dS[b,h,q,k]  (fixed order: bit-reproducible)
+__global__ __launch_bounds__(256) void dbias_reduce_kernel(const bf16_t* __restrict__ ds, float* __restrict__ dbias, int B, int HLq, int Lk, int Lkp) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)HLq * Lk) return;
+  const long row = idx / Lk;
+  const int k = idx % Lk;
+  float a = 0.f;
+  for (int b = 0; b < B; ++b) a += (float)ds[((long)b * HLq + row) * Lkp + k];
+  dbias[idx] += a;
+}
+
 template <typename K>
 static int set_lds_attr(K kern, size_t bytes) {
   if (bytes > 160 * 1024) return KLAB_ERR_UNSUPPORTED;
@@ -369,6 +386,11 @@ static int launch_bwd(const AttnMP& p, hipStream_t s) {
   if (rc) return rc;
   hipLaunchKernelGGL((t5_attn_bwd_mfma<DK>), dim3(p.B * p.H), dim3(256), lds, s, p);
   KLAB_LAUNCH_CHECK();
+  if (p.dbias && p.ds_ws) {
+    const long tot = (long)p.H * p.Lq * p.Lk;
+    hipLaunchKernelGGL(dbias_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, p.ds_ws, p.dbias, p.B, p.H * p.Lq, p.Lk, Lkp);
+    KLAB_LAUNCH_CHECK();
+  }
   return KLAB_OK;
 }
 
@@ -378,7 +400,7 @@ static AttnMP to_mp(const klab_attn_args* a) {
   p.bias = a->bias; p.causal = a->causal; p.ctx = (bf16_t*)a->ctx; p.ldo = a->ldo; p.lse = a->lse;
   p.B = a->B; p.H = a->H; p.Lq = a->Lq; p.Lk = a->Lk; p.p = a->drop_p; p.seed = a->seed_dev; p.tag = a->drop_tag;
   p.dctx = (const bf16_t*)a->dctx; p.lddo = a->lddo; p.dq = (bf16_t*)a->dq; p.lddq = a->lddq; p.dkk = (bf16_t*)a->dk_out; p.lddk = a->lddk;
-  p.dv = (bf16_t*)a->dv; p.lddv = a->lddv; p.dbias = a->dbias;
+  p.dv = (bf16_t*)a->dv; p.lddv = a->lddv; p.dbias = a->dbias; p.ds_ws = (bf16_t*)a->ds_ws;
   return p;
 }
 

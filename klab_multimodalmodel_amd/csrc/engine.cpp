@@ -107,7 +107,7 @@ struct klab_engine {
   void* kv_all = nullptr; void* dkv_all = nullptr;
   void* logits = nullptr; float *loss_row = nullptr, *inv_n = nullptr, *loss = nullptr;
   float *dh_a = nullptr, *dh_b = nullptr, *dxn = nullptr, *denc = nullptr;
-  void *dy_t = nullptr, *dctx = nullptr, *dqkv = nullptr, *dhmid = nullptr, *dqc = nullptr;
+  void *dy_t = nullptr, *dctx = nullptr, *dqkv = nullptr, *dhmid = nullptr, *dqc = nullptr, *ds_ws = nullptr;
   void *cols = nullptr, *pe_out = nullptr; float *pe_mean = nullptr, *pe_rstd = nullptr; float* x0 = nullptr; void* x0t = nullptr;
   std::vector<SwinStageBufs> sw;
   float *sw_fmean = nullptr, *sw_frstd = nullptr;
@@ -385,6 +385,10 @@ size_t plan_workspace(klab_engine* e, void* base, int B, int Ls, int Lt) {
   e->dqkv = b.take((size_t)Mx * 3 * inner * es);
   e->dhmid = b.take((size_t)Mx * ff * es);
   e->dqc = b.take((size_t)Md * inner * es);
+  {
+    const long Lmax = Le > Lt ? Le : Lt;
+    e->ds_ws = b.take((size_t)B * c.main.n_heads * Lmax * ((Lmax + 31) & ~31L) * es);
+  }
 
   // ---- Swin ----
   const klab_swin_cfg& s = c.swin;
@@ -625,7 +629,7 @@ int t5_stack_backward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Pa
       a.drop_p = p; a.seed_dev = e->seed_dev; a.drop_tag = tag_of(stack_id, i, SITE_PROB);
       a.dctx = e->dctx; a.lddo = inner; a.dq = e->dqkv; a.lddq = 3 * inner;
       a.dk_out = eoff(c, e->dqkv, inner); a.lddk = 3 * inner; a.dv = eoff(c, e->dqkv, 2 * inner); a.lddv = 3 * inner;
-      a.dbias = s.dbias;
+      a.dbias = s.dbias; a.ds_ws = e->ds_ws;
       RC(klab_t5_attn_bwd(&a, c.ws()));
     }
     RC(linear_wgrad(c, e->dqkv, 3 * inner, b.xn1, d, M, 3 * inner, d, G(l.q)));  // q|k|v grads are adjacent

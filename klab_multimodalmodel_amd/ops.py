@@ -99,7 +99,7 @@ def t5_attn_fwd(q, k, v, ctx, lse, *, B, H, Lq, Lk, dk, bias=None, causal=False,
 
 def t5_attn_bwd(q, k, v, ctx, lse, dctx, dq, dk_out, dv, *, B, H, Lq, Lk, dk, bias=None, causal=False, dbias=None,
                 drop_p=0.0, seed=None, tag=0, ldq=None, ldk=None, ldv=None, ldo=None, lddo=None, lddq=None, lddk=None,
-                lddv=None):
+                lddv=None, ds_ws=None):
     lib = L.load()
     a = _attn_args(q, k, v, ctx, lse, bias, causal, B, H, Lq, Lk, dk, drop_p, seed, tag,
                    ldq or q.stride(0), ldk or k.stride(0), ldv or v.stride(0), ldo or ctx.stride(0))
@@ -108,6 +108,7 @@ def t5_attn_bwd(q, k, v, ctx, lse, dctx, dq, dk_out, dv, *, B, H, Lq, Lk, dk, bi
     a.dk_out, a.lddk = dk_out.data_ptr(), lddk or dk_out.stride(0)
     a.dv, a.lddv = dv.data_ptr(), lddv or dv.stride(0)
     a.dbias = L.ptr(dbias)
+    a.ds_ws = L.ptr(ds_ws)
     L.check(lib.klab_t5_attn_bwd(C.byref(a), L.stream_ptr()), "klab_t5_attn_bwd")
 
 

@@ -230,7 +230,7 @@ def _attn_ref(q, k, v, bias, causal):
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("B,H,Lq,Lk,dk,causal,use_bias", [(2, 4, 7, 7, 16, True, True), (3, 2, 40, 69, 32, False, False),
+@pytest.mark.parametrize("B,H,Lq,Lk,dk,causal,use_bias", [(2, 4, 7, 7, 16, True, True), (3, 2, 40, 69, 32, False, False), (3, 2, 20, 20, 32, True, True),
                                                           (2, 8, 58, 58, 64, False, True), (2, 8, 64, 64, 64, True, True),
                                                           (1, 2, 33, 153, 64, False, False)])
 def test_t5_attention_fwd_bwd(ops, dt, B, H, Lq, Lk, dk, causal, use_bias):
@@ -258,8 +258,10 @@ def test_t5_attention_fwd_bwd(ops, dt, B, H, Lq, Lk, dk, causal, use_bias):
     dqb = torch.zeros(B * Lq, 3 * inner, device="cuda", dtype=dt)
     dkvb = torch.zeros(B * Lk, 2 * inner, device="cuda", dtype=dt)
     dbias = torch.zeros(H, Lq, Lk, device="cuda") if use_bias else None
+    # stored-dS + batch-reduction form of the bias gradient (bf16 kernels); B=2 rows of the atomics form stay covered by B=3
+    ds_ws = torch.empty(B * H * Lq * ((Lk + 31) // 32 * 32), device="cuda", dtype=dt) if (use_bias and B != 3) else None
     try:
-        ops.t5_attn_bwd(qd, kview, vview, ctx, lse, dev(dctx), dqb, dkvb[:, :inner], dkvb[:, inner:], dbias=dbias,
+        ops.t5_attn_bwd(qd, kview, vview, ctx, lse, dev(dctx), dqb, dkvb[:, :inner], dkvb[:, inner:], dbias=dbias, ds_ws=ds_ws,
                         ldq=3 * inner, ldk=2 * inner, ldv=2 * inner, lddq=3 * inner, lddk=2 * inner, lddv=2 * inner, **kw)
     except NotImplementedError:
         assert dt == torch.float32 and Lk > 128  # round-1 LDS budget of the fp32 parity mode
