@@ -88,9 +88,11 @@ __global__ __launch_bounds__(64) void swin_attn_fwd_kernel(SwinAttnP p) {
 #pragma unroll
       for (int u = 0; u < VEC; ++u) { qn[c + u] = to_f32(qv[u]); ss += qn[c + u] * qn[c + u]; }
     }
-    const float inv = scale / fmaxf(sqrtf(ss), 1e-12f);
+    // q-hat is rounded to the operand dtype BEFORE the logit scale (as the matrix-core kernel feeds it to the MFMA), so
+    // that forward and backward of either kernel family recompute bit-compatible scores
+    const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
 #pragma unroll
-    for (int c = 0; c < HD; ++c) qn[c] *= inv;
+    for (int c = 0; c < HD; ++c) qn[c] = to_f32(from_f32<T>(qn[c] * inv)) * scale;
     const int ri = reg[i];
     const float* br = p.bias + ((long)h * n + i) * n;
     float m = -INFINITY, l = 0.f;
@@ -131,6 +133,135 @@ __global__ __launch_bounds__(64) void swin_attn_fwd_kernel(SwinAttnP p) {
       *reinterpret_cast<V*>(orow + c) = ov;
     }
     if (p.lse) p.lse[(((long)b * nW + win) * H + h) * n + i] = m + __logf(l);
+  }
+}
+
+
+// ---- matrix-core forward (bf16, head dim 32, windows of <= 64 tokens: every standard Swin-V2 at 224/256 px) ----
+// One wave per (image, window, head).  K-hat (L2-normalised keys) sits in LDS as a row image, V as a transposed-read
+// image; S^T = K-hat Q-hat^T is computed swapped so that a lane owns one query column and 4 consecutive keys per tile:
+// the softmax is in-register + two shuffles, and P^T tile pairs are directly the B operand of O^T = V^T P^T (same
+// construction as t5_attn_fwd_mfma).  49-token windows are padded to 64 with -inf scores / zero V rows.
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_sw;
+__device__ __forceinline__ int swin_tr_off(int row, int col) { return (row >> 3) * 896 + (row & 7) * 96 + col * 2; }  // PD = 24 dwords
+
+__global__ __launch_bounds__(64) void swin_attn_fwd_mfma32(SwinAttnP p) {
+  constexpr int HD = 32, KP = 80;  // K row pitch: 64 B + 16 B pad
+  __shared__ __attribute__((aligned(16))) char Kr[64 * KP];
+  __shared__ __attribute__((aligned(16))) char Vt[8 * 896];
+  __shared__ int tok[64];
+  __shared__ int reg[64];
+  const int w = p.w, n = w * w, R = p.R, C = p.C, H = p.H;
+  const int nWr = R / w, nW = nWr * nWr;
+  const int lane = threadIdx.x, g = lane >> 4;
+  int bid = blockIdx.x;
+  const int h = bid % H; bid /= H;
+  const int win = bid % nW; const int b = bid / nW;
+  const int wy = win / nWr, wx = win % nWr;
+  const bf16_t* qkv = reinterpret_cast<const bf16_t*>(p.qkv);
+  const long ld = 3L * C;
+  {  // stage key/value row `lane`
+    const int j = lane;
+    bf16x8 kc[4] = {}, vc[4] = {};
+    int t = 0, rg = -1;
+    if (j < n) {
+      const int ys = wy * w + j / w, xs = wx * w + j % w;
+      const int y = (ys + p.shift) % R, x = (xs + p.shift) % R;
+      t = (b * R + y) * R + x;
+      rg = p.shift > 0 ? swin_region(ys, R, w, p.shift) * 3 + swin_region(xs, R, w, p.shift) : 0;
+      const bf16_t* kr = qkv + (long)t * ld + C + h * HD;
+      const bf16_t* vr = qkv + (long)t * ld + 2 * C + h * HD;
+      float ss = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        kc[c] = *reinterpret_cast<const bf16x8*>(kr + c * 8);
+        vc[c] = *reinterpret_cast<const bf16x8*>(vr + c * 8);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const float f = (float)kc[c][u]; ss += f * f; }
+      }
+      const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) kc[c][u] = (bf16_t)((float)kc[c][u] * inv);
+    }
+    tok[j] = t; reg[j] = rg;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      *reinterpret_cast<bf16x8*>(Kr + j * KP + c * 16) = kc[c];
+      *reinterpret_cast<bf16x8*>(Vt + swin_tr_off(j, c * 8)) = vc[c];
+    }
+  }
+  __syncthreads();
+  const float scale = __expf(fminf(p.logit_scale[h], 4.6051701859880914f));
+  bf16_t* ctx = reinterpret_cast<bf16_t*>(p.ctx);
+  const int nqt = (n + 15) / 16;
+  for (int qt = 0; qt < nqt; ++qt) {
+    const int q = qt * 16 + (lane & 15);
+    const int qc = q < n ? q : n - 1;
+    const int tq = tok[qc], rq = reg[qc];
+    // Q-hat fragment: 8 of the row's 32 values per lane; the row norm is completed across the 4 lane groups
+    bf16x8 qv = *reinterpret_cast<const bf16x8*>(qkv + (long)tq * ld + h * HD + g * 8);
+    float ss = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const float f = (float)qv[u]; ss += f * f; }
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    const float qs = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) qv[u] = (bf16_t)((float)qv[u] * qs);
+    f32x4 st[4];
+    float m = -INFINITY;
+    const float* brow = p.bias + ((long)h * n + qc) * n;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kr + (t * 16 + (lane & 15)) * KP + g * 16);
+      st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qv, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = t * 16 + g * 4 + r;
+        float x = -INFINITY;
+        if (key < n) {
+          x = st[t][r] * scale + brow[key];
+          if (reg[key] != rq) x += -200.f;  // -100 twice (HF/swinv2:433-436)
+        }
+        st[t][r] = x;
+        m = fmaxf(m, x);
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float e = __expf(st[t][r] - m); st[t][r] = e; sum += e; }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+    f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      const f32x4 a = st[2 * sidx], bb = st[2 * sidx + 1];
+      const bf16x8 pf = {(bf16_t)(a[0] * inv), (bf16_t)(a[1] * inv), (bf16_t)(a[2] * inv), (bf16_t)(a[3] * inv),
+                         (bf16_t)(bb[0] * inv), (bf16_t)(bb[1] * inv), (bf16_t)(bb[2] * inv), (bf16_t)(bb[3] * inv)};
+      const int q4 = (lane & 15) >> 2, pp = lane & 3;
+      const int r0 = sidx * 32 + 4 * g + q4;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_sw*)(Vt + swin_tr_off(r0, dt * 16 + 4 * pp)));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_sw*)(Vt + swin_tr_off(r0 + 16, dt * 16 + 4 * pp)));
+        const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+      }
+    }
+    if (q < n) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+        *reinterpret_cast<bf16x4*>(ctx + (long)tq * C + h * HD + dt * 16 + g * 4) =
+            bf16x4{(bf16_t)o[dt][0], (bf16_t)o[dt][1], (bf16_t)o[dt][2], (bf16_t)o[dt][3]};
+      if (g == 0 && p.lse) p.lse[(((long)b * nW + win) * H + h) * n + q] = m + __logf(sum);
+    }
   }
 }
 
@@ -212,7 +343,7 @@ __global__ __launch_bounds__(64) void swin_attn_bwd_kernel(SwinAttnP p) {
     }
     const float qinv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
 #pragma unroll
-    for (int c = 0; c < HD; ++c) qh[c] *= qinv;  // unit q-hat (unscaled)
+    for (int c = 0; c < HD; ++c) qh[c] = to_f32(from_f32<T>(qh[c] * qinv));  // unit q-hat (unscaled), operand-dtype rounding as in forward
     const int ri = reg[i];
     const float* br = p.bias + ((long)h * n + i) * n;
     const float lse = p.lse[(((long)b * nW + win) * H + h) * n + i];
@@ -392,6 +523,12 @@ extern "C" int klab_swin_attn_fwd(const klab_swin_attn_args* a, void* stream) {
   const int hd = a->C / a->H;
   hipStream_t s = (hipStream_t)stream;
   if (a->dtype == KLAB_BF16) {
+    if (hd == 32 && a->w * a->w <= 64 && (a->C & 7) == 0) {
+      const int nW = (a->R / a->w) * (a->R / a->w);
+      hipLaunchKernelGGL(swin_attn_fwd_mfma32, dim3(a->B * nW * a->H), dim3(64), 0, s, p);
+      KLAB_LAUNCH_CHECK();
+      return KLAB_OK;
+    }
     if (hd == 32) return launch_swin_fwd<bf16_t, 32>(p, s);
     if (hd == 16) return launch_swin_fwd<bf16_t, 16>(p, s);
   } else if (a->dtype == KLAB_F32) {

@@ -342,7 +342,7 @@ def test_swin_window_attention_fwd_bwd(ops, dt, B, R, w, shift, H, C):
     dqkv = torch.empty(B * R * R, 3 * C, device="cuda", dtype=dt)
     dbias, dls = torch.zeros(H, n, n, device="cuda"), torch.zeros(H, device="cuda")
     ops.swin_attn_bwd(dev(qkv), ctx, dev(bias), dev(ls), lse, dev(dctx), dqkv, dbias, dls, **kw)
-    t = tol(dt) * 3
+    t = tol(dt) * 4  # cosine logits are scaled by up to 100: bf16 rounding of q-hat / k-hat is amplified accordingly
     assert rel_l2(dqkv.float().cpu(), qr.grad) < t
     assert rel_l2(dbias.cpu(), br.grad) < t
     assert rel_l2(dls.cpu(), lr.grad) < t * 10  # scalar aggregated over all windows with fast-exp probabilities
