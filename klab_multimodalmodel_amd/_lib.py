@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libklab_mm.so")
+LIB_PATH = os.environ.get("KLAB_LIB", os.path.join(HERE, "libklab_mm.so"))  # KLAB_LIB: A/B-test another build
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2

@@ -114,6 +114,9 @@ struct klab_engine {
   // swin backward scratch
   float *sdh_a = nullptr, *sdh_b = nullptr, *sdm = nullptr; void *sdy = nullptr, *sdctx = nullptr, *sdqkv = nullptr, *sda = nullptr;
   float *sdbias = nullptr, *sdtable = nullptr;
+  // side stream: independent chains run beside the main one (frozen language encoder || Swin; weight gradients ||
+  // the activation-gradient chain); joined back with events before anything the caller can observe
+  hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // probe: HIP events around the LM-head GEMM of each forward
   bool probe_on = false; std::vector<hipEvent_t> ev0, ev1; int probe_n = 0;
   float p_train = 0.f;   // dropout prob in effect for the last forward (0 in eval)
@@ -737,7 +740,15 @@ extern "C" klab_engine* klab_engine_create(const klab_model_cfg* cfg) {
   return e;
 }
 
-extern "C" void klab_engine_destroy(klab_engine* e) { delete e; }
+extern "C" void klab_engine_destroy(klab_engine* e) {
+  if (!e) return;
+  if (e->ev_fork) hipEventDestroy(e->ev_fork);
+  if (e->ev_join) hipEventDestroy(e->ev_join);
+  if (e->side) hipStreamDestroy(e->side);
+  for (auto ev : e->ev0) hipEventDestroy(ev);
+  for (auto ev : e->ev1) hipEventDestroy(ev);
+  delete e;
+}
 
 extern "C" int klab_engine_num_params(const klab_engine* e, int model) {
   if (!e || model < 0 || model > 2) return -1;
@@ -839,6 +850,11 @@ extern "C" int klab_engine_bind(klab_engine* e, int B, int Ls, int Lt, void* wor
     }
   }
   RC((int)hipMemsetAsync(e->seed_dev, 0, 256, hs));
+  if (!e->side) {
+    RC((int)hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+    RC((int)hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    RC((int)hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+  }
   e->bound = true;
   return 0;
 }
@@ -856,13 +872,22 @@ extern "C" int klab_engine_forward(klab_engine* e, const float* pixels, const lo
   RC(klab_cast_pack(e->cast_desc, e->n_cast, e->cast_total4, e->warena, c.dt, c.ws()));
   if (e->n_fcast) RC(klab_cast_pack(e->fcast_desc, e->n_fcast, e->fcast_total4, e->farena, KLAB_F32, c.ws()));
   const int B = e->B, d = cfg.main.d_model;
-  // 2. frozen language encoder, eval mode (ref/models/model.py:20-21) -> rows [N_img, Le) of enc.h[0]
-  RC(klab_embed_fwd(src_ids, 0, e->Ls, 0, 0, e->W[1][e->li.shared], cfg.lang.vocab, e->lang.h[0], B * e->Ls, d, 0.f, nullptr, 0, e->err_dev,
-                    c.ws()));
-  RC(t5_stack_forward(c, cfg.lang, e->P[1], e->W[1], e->li.enc, e->li.enc_final, e->lang, false, STACK_LANG, 0.f, B, nullptr, 0, 0,
-                      e->enc.h[0], e->Ls, e->Le, e->Nimg, p));
-  // 3. Swin-V2 (ref/models/model.py:22) -> rows [0, N_img)
+  // 2./3. The two frozen-or-not towers are independent until the concat.  Swin-V2 (ref/models/model.py:22, rows
+  //    [0, N_img)) is enqueued FIRST on the main stream -- its launches are long, so the host runs far ahead -- and
+  //    the frozen language encoder (model.py:20-21, rows [N_img, Le); ~100 launches of ~5 us over 576 tokens, which
+  //    would otherwise be paced by the host) is then enqueued on the side stream and runs underneath it.
+  RC((int)hipEventRecord(e->ev_fork, c.s));
   RC(swin_forward(c, pixels, p));
+  RC((int)hipStreamWaitEvent(e->side, e->ev_fork, 0));
+  {
+    Ctx cs{e, e->side, e->cfg.dtype, e->es};
+    RC(klab_embed_fwd(src_ids, 0, e->Ls, 0, 0, e->W[1][e->li.shared], cfg.lang.vocab, e->lang.h[0], B * e->Ls, d, 0.f, nullptr, 0, e->err_dev,
+                      cs.ws()));
+    RC(t5_stack_forward(cs, cfg.lang, e->P[1], e->W[1], e->li.enc, e->li.enc_final, e->lang, false, STACK_LANG, 0.f, B, nullptr, 0, 0,
+                        e->enc.h[0], e->Ls, e->Le, e->Nimg, p));
+    RC((int)hipEventRecord(e->ev_join, e->side));
+  }
+  RC((int)hipStreamWaitEvent(c.s, e->ev_join, 0));
   // 4. T5 encoder (HF/t5:1009-1016)
   RC(t5_stack_forward(c, cfg.main, e->P[2], e->W[2], e->mi.enc, e->mi.enc_final, e->enc, false, STACK_ENC, p, B, nullptr, 0, 0, nullptr, 0, 0, 0,
                       p));

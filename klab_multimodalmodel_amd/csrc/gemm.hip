@@ -19,6 +19,10 @@
 #include "common.h"
 #include "klab_mm.h"
 
+#ifndef KLAB_GLDS_STAGES
+#define KLAB_GLDS_STAGES 4
+#endif
+
 namespace klab {
 
 template <typename T> struct MmaTraits;
@@ -412,7 +416,7 @@ struct GldsOperand {
 template <int BM, int BN, bool AK, bool BKM, bool ATOMIC>
 __device__ __forceinline__ void gemm_glds_body(const GemmP& p) {
   typedef bf16_t T;
-  constexpr int BK = 32, S = 4;
+  constexpr int BK = 32, S = KLAB_GLDS_STAGES;
   constexpr int WTM = BM / 2, WTN = BN / 2, MI = WTM / 16, NI = WTN / 16;
   typedef GldsOperand<BM, AK> OA;
   typedef GldsOperand<BN, BKM> OB;
@@ -466,6 +470,7 @@ __device__ __forceinline__ void gemm_glds_body(const GemmP& p) {
   for (int t = 0; t < nt; ++t) {
     const int ahead = nt - 1 - t;  // k-tiles issued after tile t that may stay in flight
     if (ahead >= S - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * LPS) : "memory");
+    else if (S > 3 && ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
     else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // tile t visible to every wave; every wave is done reading tile t-1's stage
@@ -679,7 +684,7 @@ static int launch_gemm(const GemmP& p, bool atomic, hipStream_t s) {
 template <int BM, int BN, bool AK, bool BKM>
 static int launch_glds(const GemmP& p, bool atomic, hipStream_t s) {
   const int nt = (p.K / 32 + p.splits - 1) / p.splits;
-  size_t lds = (size_t)(nt < 4 ? nt : 4) * (BM + BN) * 64;  // short K: fewer stages => more workgroups per CU
+  size_t lds = (size_t)(nt < KLAB_GLDS_STAGES ? nt : KLAB_GLDS_STAGES) * (BM + BN) * 64;  // short K: fewer stages => more workgroups per CU
   if (!atomic) {
     const size_t epi = (size_t)epilogue_lds_bytes<BM, BN>(p.c_f32);
     if (epi > lds) lds = epi;
@@ -774,7 +779,7 @@ extern "C" int klab_gemm(const klab_gemm_args* a, void* stream) {
   if (a->name_tag == 1 && a->a_kmajor && a->b_kmajor) {
     if (a->dtype == KLAB_BF16) {
       if (a->K % 32) return KLAB_ERR_UNSUPPORTED;
-      size_t lds = 4 * (size_t)(128 + 128) * 64;
+      size_t lds = KLAB_GLDS_STAGES * (size_t)(128 + 128) * 64;
       const size_t epi = (size_t)epilogue_lds_bytes<128, 128>(p.c_f32);
       return launch_kernel(klab_lmhead_gemm<bf16_t>, p, 128, 128, epi > lds ? epi : lds, s);
     }

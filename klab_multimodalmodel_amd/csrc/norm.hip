@@ -147,33 +147,42 @@ __global__ __launch_bounds__(256) void rmsnorm_dw_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------
 // LayerNorm forward (Swin-V2): out = shortcut + (LN(y) * gamma + beta); optional T copy.
 // ------------------------------------------------------------------------------------------
-template <typename TI, typename TO>
+// LPR = lanes per row (16 for C = 64, 32 for C = 128, 64 otherwise): narrow Swin stage-0/1 rows are packed 4 / 2 per
+// wave so that every lane streams 16 B (with one row per wave, C = 64 kept 16 of 64 lanes busy).
+template <typename TI, typename TO, int LPR>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const TI* __restrict__ y, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const float* __restrict__ shortcut,
                                                             float* __restrict__ out, TO* __restrict__ outt, float* __restrict__ mean,
                                                             float* __restrict__ rstd, int rows, int C, float eps, int grp,
                                                             int grp_stride, int off, float p, const uint32_t* seed, uint32_t tag) {
+  constexpr int RPW = 64 / LPR;  // rows per wave
   const int lane = threadIdx.x & 63;
+  const int sub = lane / LPR, l = lane % LPR;
   const int wpb = blockDim.x >> 6;
   const DropCtx dc = make_drop(seed, tag, p);
-  for (long row = (long)blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * wpb) {
-    const TI* yr = y + row * C;
+  for (long row0 = ((long)blockIdx.x * wpb + (threadIdx.x >> 6)) * RPW; row0 < rows; row0 += (long)gridDim.x * wpb * RPW) {
+    const long row = row0 + sub;
+    const bool live = row < rows;
+    const TI* yr = y + (live ? row : 0) * C;
     float s = 0.f;
-    for (int c = lane * 4; c < C; c += 256) {
-      f32x4 v = load4<TI>(yr + c);
-      s += v[0] + v[1] + v[2] + v[3];
-    }
-    const float mu = wave_sum(s) / (float)C;
+    if (live)
+      for (int c = l * 4; c < C; c += LPR * 4) {
+        f32x4 v = load4<TI>(yr + c);
+        s += v[0] + v[1] + v[2] + v[3];
+      }
+    const float mu = group_sum<LPR>(s) / (float)C;
     float ss = 0.f;
-    for (int c = lane * 4; c < C; c += 256) {
-      f32x4 v = load4<TI>(yr + c);
+    if (live)
+      for (int c = l * 4; c < C; c += LPR * 4) {
+        f32x4 v = load4<TI>(yr + c);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { float t = v[i] - mu; ss += t * t; }
-    }
-    const float r = rsqrtf(wave_sum(ss) / (float)C + eps);
-    if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = r; }
+        for (int i = 0; i < 4; ++i) { float t = v[i] - mu; ss += t * t; }
+      }
+    const float r = rsqrtf(group_sum<LPR>(ss) / (float)C + eps);
+    if (!live) continue;
+    if (l == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = r; }
     const long orow = remap_row(row, grp, grp_stride, off);
-    for (int c = lane * 4; c < C; c += 256) {
+    for (int c = l * 4; c < C; c += LPR * 4) {
       f32x4 v = load4<TI>(yr + c);
       f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
       f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
@@ -326,9 +335,18 @@ extern "C" int klab_layernorm_fwd(const void* y, int y_dtype, const float* gamma
   if (rows == 0) return KLAB_OK;
   hipStream_t s = (hipStream_t)stream;
   const int g = norm_grid(rows);
-#define LN_LAUNCH(TI, TO)                                                                                             \
-  hipLaunchKernelGGL((layernorm_fwd_kernel<TI, TO>), dim3(g), dim3(256), 0, s, (const TI*)y, gamma, beta, shortcut, out, \
-                     (TO*)outt, mean, rstd, rows, C, eps, grp, grp_stride, off, drop_p, seed_dev, tag)
+#define LN_LAUNCH(TI, TO)                                                                                                         \
+  do {                                                                                                                            \
+    if (C <= 64)                                                                                                                  \
+      hipLaunchKernelGGL((layernorm_fwd_kernel<TI, TO, 16>), dim3(norm_grid((rows + 3) / 4)), dim3(256), 0, s, (const TI*)y, gamma, beta, \
+                         shortcut, out, (TO*)outt, mean, rstd, rows, C, eps, grp, grp_stride, off, drop_p, seed_dev, tag);        \
+    else if (C <= 128)                                                                                                            \
+      hipLaunchKernelGGL((layernorm_fwd_kernel<TI, TO, 32>), dim3(norm_grid((rows + 1) / 2)), dim3(256), 0, s, (const TI*)y, gamma, beta, \
+                         shortcut, out, (TO*)outt, mean, rstd, rows, C, eps, grp, grp_stride, off, drop_p, seed_dev, tag);        \
+    else                                                                                                                          \
+      hipLaunchKernelGGL((layernorm_fwd_kernel<TI, TO, 64>), dim3(g), dim3(256), 0, s, (const TI*)y, gamma, beta, shortcut, out,  \
+                         (TO*)outt, mean, rstd, rows, C, eps, grp, grp_stride, off, drop_p, seed_dev, tag);                       \
+  } while (0)
   if (y_dtype == KLAB_BF16 && outt_dtype == KLAB_BF16) LN_LAUNCH(bf16_t, bf16_t);
   else if (y_dtype == KLAB_BF16) LN_LAUNCH(bf16_t, float);
   else if (outt_dtype == KLAB_BF16) LN_LAUNCH(float, bf16_t);
