@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE configs[1]: 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the engine's launch sequences as hipGraphs (measured: no gain "
+                    "while the step is GPU-bound; kept for when it becomes launch-bound)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -130,6 +132,7 @@ def main():
     else:
         core = model
         core._direct_grads = True  # grads land in the flat buffer (no autograd copies); same math
+    core.use_graph = bool(a.graph)  # forward / backward launch sequences replayed as hipGraphs (same kernels, same math)
     optimizer = torch.optim.Adam(core.transformer.parameters(), lr=1e-3, fused=True)  # ref/train.py:28 (same optimizer class, fused multi-tensor kernel)
     core.transformer.train()                                               # ref/train.py:52
 
@@ -176,7 +179,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: Swin-V2(C=64,(2,2,6,2),224,w7) frozen + T5-small, fwd+bwd+Adam, "
                                    "T5 dropout 0.1 on, random-init weights",
                        "global_batch": world * B, "per_gpu_batch": B, "src_len": Ls, "tgt_len": Lt,
-                       "parallelism": f"dp{world}", "fwd_bwd_gflop_per_sample": GFLOP_PER_SAMPLE["cfg2"],
+                       "parallelism": f"dp{world}", "hipgraph": bool(core.use_graph), "fwd_bwd_gflop_per_sample": GFLOP_PER_SAMPLE["cfg2"],
                        "step_mfma_frac": round(B * GFLOP_PER_SAMPLE["cfg2"] / (ms * 1e-3) / 1e3 / PEAK_BF16_TFLOPS, 4),
                        "final_loss": round(lossv, 4)},
         }

@@ -212,9 +212,13 @@ int klab_engine_bind(klab_engine* e, int B, int Ls, int Lt, void* workspace, siz
                      const int* lang_bucket, const int* enc_bucket, const int* dec_bucket, const void* const* swin_coords,
                      const void* const* swin_index, void* stream);
 /* pixels [B,3,H,W] f32, src_ids [B,Ls] / tgt_ids [B,Lt] int64 (device).  training: T5 dropout on
- * (model.module.transformer.train(), ref/train.py:52).  The loss lands in *klab_engine_loss_ptr.  */
+ * (model.module.transformer.train(), ref/train.py:52).  `seed` (re)bases the device-side counter RNG whenever
+ * it changes; every forward advances the counter itself.  The loss lands in *klab_engine_loss_ptr.      */
 int klab_engine_forward(klab_engine* e, const float* pixels, const long long* src_ids, const long long* tgt_ids, int training,
                         uint32_t seed, int want_grad, void* stream);
+/* hipGraph replay of the forward / backward launch sequences (first use eager, second captured, then replayed;
+ * inputs are staged into engine-owned buffers so node addresses stay fixed).  Off by default.          */
+int klab_engine_set_graph(klab_engine* e, int on);
 /* segment 0: LM head + decoder + tied embedding; 1: encoder; 2: Swin (no-op unless train_swin).
  * dloss_dev: device scalar d(objective)/d(loss) (NULL = 1).                                       */
 int klab_engine_backward(klab_engine* e, int segment, const float* dloss_dev, void* stream);

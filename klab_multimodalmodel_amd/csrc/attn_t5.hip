@@ -243,11 +243,7 @@ __global__ __launch_bounds__(256) void t5_attn_bwd_kernel(AttnP p) {
 }
 
 template <typename K>
-static int set_lds(K kern, size_t bytes) {
-  if (bytes > 160 * 1024) return KLAB_ERR_UNSUPPORTED;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  return e == hipSuccess ? KLAB_OK : (int)e;
-}
+static int set_lds(K kern, size_t bytes) { return ensure_dyn_lds(reinterpret_cast<const void*>(kern), bytes); }
 
 }  // namespace klab
 

@@ -351,11 +351,7 @@ __global__ __launch_bounds__(256) void dbias_reduce_kernel(const bf16_t* __restr
 }
 
 template <typename K>
-static int set_lds_attr(K kern, size_t bytes) {
-  if (bytes > 160 * 1024) return KLAB_ERR_UNSUPPORTED;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  return e == hipSuccess ? KLAB_OK : (int)e;
-}
+static int set_lds_attr(K kern, size_t bytes) { return ensure_dyn_lds(reinterpret_cast<const void*>(kern), bytes); }
 
 template <int DK>
 static int launch_fwd(const AttnMP& p, hipStream_t s) {

@@ -24,6 +24,10 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 namespace klab {
 
+// raise a kernel's dynamic-LDS limit once per (kernel, size): hipFuncSetAttribute is not a stream operation and must
+// not be issued while the stream is being captured into a hipGraph (misc.hip)
+int ensure_dyn_lds(const void* kernel, size_t bytes);
+
 template <typename T> struct TypeTag;
 template <> struct TypeTag<float> { static constexpr int id = KLAB_F32; };
 template <> struct TypeTag<bf16_t> { static constexpr int id = KLAB_BF16; };

@@ -117,6 +117,17 @@ struct klab_engine {
   // side stream: independent chains run beside the main one (frozen language encoder || Swin; weight gradients ||
   // the activation-gradient chain); joined back with events before anything the caller can observe
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // stream capture is illegal on the legacy default stream (where PyTorch runs unless told otherwise): in graph mode
+  // calls arriving on stream 0 are executed on this engine-owned stream, fenced in and out with events
+  hipStream_t own = nullptr; hipEvent_t ev_in = nullptr, ev_out = nullptr;
+  // hipGraph replay of the (allocation-free, sync-free) launch sequences: [0..1] forward up to the LM head by
+  // training flag, [2..3] cross-entropy by want_grad, [4..6] backward segments.  First use runs eagerly (sets
+  // kernel attributes), second use captures, later uses replay.  Rebinding drops them.
+  bool use_graph = false;
+  struct GraphSlot { hipGraphExec_t exec = nullptr; int uses = 0; bool failed = false; } gs[7];
+  // engine-owned copies of the per-step inputs: graph nodes need stable addresses
+  float* pixels_buf = nullptr; long long *src_buf = nullptr, *tgt_buf = nullptr; float* dloss_buf = nullptr;
+  uint32_t seed_base = 0; bool seed_set = false;
   // probe: HIP events around the LM-head GEMM of each forward
   bool probe_on = false; std::vector<hipEvent_t> ev0, ev1; int probe_n = 0;
   float p_train = 0.f;   // dropout prob in effect for the last forward (0 in eval)
@@ -362,10 +373,14 @@ size_t plan_workspace(klab_engine* e, void* base, int B, int Ls, int Lt) {
   const long Me = (long)B * Le, Md = (long)B * Lt;
   const int nld = c.main.n_dec_layers;
 
-  e->seed_dev = (uint32_t*)b.take(256);
+  e->seed_dev = (uint32_t*)b.take(512);   // [0] seed of the current step, [1] base, [2] step counter
   e->err_dev = (int*)((char*)e->seed_dev + 64);
   e->inv_n = (float*)((char*)e->seed_dev + 128);
   e->loss = (float*)((char*)e->seed_dev + 192);
+  e->dloss_buf = (float*)((char*)e->seed_dev + 256);
+  e->pixels_buf = (float*)b.take((size_t)B * c.swin.in_ch * c.swin.image_size * c.swin.image_size * 4);
+  e->src_buf = (long long*)b.take((size_t)B * Ls * 8);
+  e->tgt_buf = (long long*)b.take((size_t)B * Lt * 8);
   e->warena = b.take((size_t)e->warena_elems * es);
   e->farena = (float*)b.take((size_t)e->farena_elems * 4);
   e->cast_desc = b.take(sizeof(long) * 3 * (e->P[0].size() + e->P[1].size() + e->P[2].size() + 1));
@@ -745,6 +760,10 @@ extern "C" void klab_engine_destroy(klab_engine* e) {
   if (e->ev_fork) hipEventDestroy(e->ev_fork);
   if (e->ev_join) hipEventDestroy(e->ev_join);
   if (e->side) hipStreamDestroy(e->side);
+  if (e->ev_in) hipEventDestroy(e->ev_in);
+  if (e->ev_out) hipEventDestroy(e->ev_out);
+  if (e->own) hipStreamDestroy(e->own);
+  for (auto& g : e->gs) if (g.exec) hipGraphExecDestroy(g.exec);
   for (auto ev : e->ev0) hipEventDestroy(ev);
   for (auto ev : e->ev1) hipEventDestroy(ev);
   delete e;
@@ -849,33 +868,87 @@ extern "C" int klab_engine_bind(klab_engine* e, int B, int Ls, int Lt, void* wor
       if (er != hipSuccess) return (int)er;
     }
   }
-  RC((int)hipMemsetAsync(e->seed_dev, 0, 256, hs));
+  RC((int)hipMemsetAsync(e->seed_dev, 0, 512, hs));
+  for (auto& g : e->gs) {
+    if (g.exec) hipGraphExecDestroy(g.exec);
+    g = klab_engine::GraphSlot();
+  }
+  e->seed_set = false;
   if (!e->side) {
     RC((int)hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
     RC((int)hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     RC((int)hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+    RC((int)hipStreamCreateWithFlags(&e->own, hipStreamNonBlocking));
+    RC((int)hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
+    RC((int)hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming));
   }
   e->bound = true;
   return 0;
 }
 
-extern "C" int klab_engine_forward(klab_engine* e, const float* pixels, const long long* src_ids, const long long* tgt_ids, int training,
-                                   uint32_t seed, int want_grad, void* stream) {
-  if (!e || !e->bound || !pixels || !src_ids || !tgt_ids) return KLAB_ERR_BADARG;
-  Ctx c{e, (hipStream_t)stream, e->cfg.dtype, e->es};
+namespace {
+
+__global__ void seed_set_kernel(uint32_t* st, uint32_t base) { st[1] = base; st[2] = 0; }
+__global__ void seed_step_kernel(uint32_t* st) {
+  const uint32_t n = st[2] + 1;
+  st[2] = n;
+  uint32_t x = st[1] + 0x9E3779B1u * n;
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  st[0] = x;
+}
+
+// the stream the engine really works on for this call, and the fences that tie it to the caller's stream
+inline hipStream_t enter_stream(klab_engine* e, hipStream_t caller, int& rc) {
+  rc = 0;
+  if (!e->use_graph || caller != nullptr) return caller;
+  rc = (int)hipEventRecord(e->ev_in, caller);
+  if (!rc) rc = (int)hipStreamWaitEvent(e->own, e->ev_in, 0);
+  return e->own;
+}
+inline int leave_stream(klab_engine* e, hipStream_t caller, hipStream_t used) {
+  if (used == caller) return 0;
+  int rc = (int)hipEventRecord(e->ev_out, used);
+  if (!rc) rc = (int)hipStreamWaitEvent(caller, e->ev_out, 0);
+  return rc;
+}
+
+template <typename F>
+int run_graphed(klab_engine* e, int slot, hipStream_t s, F body) {
+  klab_engine::GraphSlot& g = e->gs[slot];
+  if (!e->use_graph || g.failed) return body();
+  if (g.exec) return (int)hipGraphLaunch(g.exec, s);
+  if (g.uses++ == 0) return body();  // first use eager: kernel attributes (dynamic LDS sizes) get set outside capture
+  hipError_t er = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+  if (er != hipSuccess) { g.failed = true; return body(); }
+  const int rc = body();
+  hipGraph_t graph = nullptr;
+  er = hipStreamEndCapture(s, &graph);
+  if (rc != 0 || er != hipSuccess || !graph) {
+    if (graph) hipGraphDestroy(graph);
+    g.failed = true;
+    return rc != 0 ? rc : body();  // capture enqueued nothing: run the sequence for real
+  }
+  er = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+  hipGraphDestroy(graph);
+  if (er != hipSuccess) { g.exec = nullptr; g.failed = true; return body(); }
+  return (int)hipGraphLaunch(g.exec, s);
+}
+
+// everything of the forward before the LM head (inputs are the engine-owned staged copies)
+int forward_part_a(klab_engine* e, hipStream_t stream, float p) {
+  Ctx c{e, stream, e->cfg.dtype, e->es};
   const klab_model_cfg& cfg = e->cfg;
-  const float p = training ? cfg.main.dropout : 0.f;
-  e->p_train = p;
-  e->last_tgt = tgt_ids;
-  RC((int)hipMemcpyAsync(e->seed_dev, &seed, 4, hipMemcpyHostToDevice, c.s));  // pageable 4-byte copy: value captured at call time
+  const float* pixels = e->pixels_buf;
+  const long long *src_ids = e->src_buf, *tgt_ids = e->tgt_buf;
+  hipLaunchKernelGGL(seed_step_kernel, dim3(1), dim3(1), 0, c.s, e->seed_dev);
   // 1. weights: fp32 masters -> compute-dtype arena (+ fused f32 bias vectors)
   RC(klab_cast_pack(e->cast_desc, e->n_cast, e->cast_total4, e->warena, c.dt, c.ws()));
   if (e->n_fcast) RC(klab_cast_pack(e->fcast_desc, e->n_fcast, e->fcast_total4, e->farena, KLAB_F32, c.ws()));
   const int B = e->B, d = cfg.main.d_model;
-  // 2./3. The two frozen-or-not towers are independent until the concat.  Swin-V2 (ref/models/model.py:22, rows
-  //    [0, N_img)) is enqueued FIRST on the main stream -- its launches are long, so the host runs far ahead -- and
-  //    the frozen language encoder (model.py:20-21, rows [N_img, Le); ~100 launches of ~5 us over 576 tokens, which
-  //    would otherwise be paced by the host) is then enqueued on the side stream and runs underneath it.
+  // 2./3. The two towers are independent until the concat.  Swin-V2 (ref/models/model.py:22, rows [0, N_img)) is
+  //    enqueued FIRST on the main stream -- its launches are long, so the host runs far ahead -- and the frozen
+  //    language encoder (model.py:20-21, rows [N_img, Le); ~100 launches of ~5 us over 576 tokens, which would
+  //    otherwise be paced by the host) is then enqueued on the side stream and runs underneath it.
   RC((int)hipEventRecord(e->ev_fork, c.s));
   RC(swin_forward(c, pixels, p));
   RC((int)hipStreamWaitEvent(e->side, e->ev_fork, 0));
@@ -891,25 +964,61 @@ extern "C" int klab_engine_forward(klab_engine* e, const float* pixels, const lo
   // 4. T5 encoder (HF/t5:1009-1016)
   RC(t5_stack_forward(c, cfg.main, e->P[2], e->W[2], e->mi.enc, e->mi.enc_final, e->enc, false, STACK_ENC, p, B, nullptr, 0, 0, nullptr, 0, 0, 0,
                       p));
-  // 5. decoder: shift_right + embedding (HF/t5:1026-1028), cross K/V of all layers in one GEMM, stack, LM head + CE
+  // 5. decoder: shift_right + embedding (HF/t5:1026-1028), cross K/V of all layers in one GEMM, stack
   const int inner = cfg.main.n_heads * cfg.main.d_kv, nld = cfg.main.n_dec_layers;
   RC(klab_embed_fwd(tgt_ids, 1, e->Lt, cfg.main.start_id, cfg.main.pad_id, e->W[2][e->mi.shared], cfg.main.vocab, e->dec.h[0], B * e->Lt, d, p,
                     e->seed_dev, tag_of(STACK_DEC, 0, SITE_IN), e->err_dev, c.ws()));
   RC(linear_fwd(c, e->enc.out_t, B * e->Le, d, e->kvall_w_off, nld * 2 * inner, e->kv_all, (long)nld * 2 * inner, c.dt));
   RC(t5_stack_forward(c, cfg.main, e->P[2], e->W[2], e->mi.dec, e->mi.dec_final, e->dec, true, STACK_DEC, p, B, e->kv_all, e->Le,
                       (long)nld * 2 * inner, nullptr, 0, 0, 0, p));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int klab_engine_set_graph(klab_engine* e, int on) {
+  if (!e) return KLAB_ERR_BADARG;
+  e->use_graph = on != 0;
+  return 0;
+}
+
+extern "C" int klab_engine_forward(klab_engine* e, const float* pixels, const long long* src_ids, const long long* tgt_ids, int training,
+                                   uint32_t seed, int want_grad, void* stream) {
+  if (!e || !e->bound || !pixels || !src_ids || !tgt_ids) return KLAB_ERR_BADARG;
+  int erc = 0;
+  const hipStream_t xs = enter_stream(e, (hipStream_t)stream, erc);
+  if (erc) return erc;
+  Ctx c{e, xs, e->cfg.dtype, e->es};
+  const klab_model_cfg& cfg = e->cfg;
+  const float p = training ? cfg.main.dropout : 0.f;
+  e->p_train = p;
+  e->last_tgt = e->tgt_buf;
+  // stage the inputs (device-to-device, stream-ordered): replayed graphs read fixed addresses
+  const int B = e->B, d = cfg.main.d_model;
+  RC((int)hipMemcpyAsync(e->pixels_buf, pixels, (size_t)B * cfg.swin.in_ch * cfg.swin.image_size * cfg.swin.image_size * 4,
+                         hipMemcpyDeviceToDevice, c.s));
+  RC((int)hipMemcpyAsync(e->src_buf, src_ids, (size_t)B * e->Ls * 8, hipMemcpyDeviceToDevice, c.s));
+  RC((int)hipMemcpyAsync(e->tgt_buf, tgt_ids, (size_t)B * e->Lt * 8, hipMemcpyDeviceToDevice, c.s));
+  if (!e->seed_set || seed != e->seed_base) {  // (re)seed the device-side counter RNG; each forward then advances it itself
+    hipLaunchKernelGGL(seed_set_kernel, dim3(1), dim3(1), 0, c.s, e->seed_dev, seed);
+    e->seed_base = seed; e->seed_set = true;
+  }
+  RC(run_graphed(e, training ? 1 : 0, c.s, [&]() { return forward_part_a(e, c.s, p); }));
   {
     const int Md = B * e->Lt, V = cfg.main.vocab;
     klab_gemm_args g = G0(c, Md, V, d, e->dec.out_t, d, 1, woff(c, e->P[2][e->mi.shared].warena_off), d, 1, e->logits, V, c.dt);
     g.alpha = cfg.main.scale_decoder_outputs ? 1.f / sqrtf((float)d) : 1.f;  // HF/t5:1044-1045
     g.name_tag = 1;
+    // the LM-head launch stays outside the graphs so that the probe's HIP events can bracket it
     const bool probe = e->probe_on && e->probe_n < (int)e->ev0.size();
     if (probe) RC((int)hipEventRecord(e->ev0[e->probe_n], c.s));
     RC(klab_gemm(&g, c.ws()));
     if (probe) { RC((int)hipEventRecord(e->ev1[e->probe_n], c.s)); ++e->probe_n; }
-    RC(klab_ce_fwd(e->logits, V, c.dt, tgt_ids, Md, V, e->inv_n, e->loss_row, e->loss, want_grad, c.ws()));
+    RC(run_graphed(e, want_grad ? 3 : 2, c.s, [&]() {
+      return klab_ce_fwd(e->logits, V, c.dt, e->tgt_buf, Md, V, e->inv_n, e->loss_row, e->loss, want_grad, c.ws());
+    }));
   }
-  return 0;
+  return leave_stream(e, (hipStream_t)stream, xs);
 }
 
 extern "C" int klab_engine_probe_enable(klab_engine* e, int on) {
@@ -953,8 +1062,7 @@ extern "C" const void* klab_engine_buffer(const klab_engine* e, const char* name
 }
 
 // segment 0: LM head + decoder + shared embedding; 1: encoder; 2: Swin
-extern "C" int klab_engine_backward(klab_engine* e, int segment, const float* dloss_dev, void* stream) {
-  if (!e || !e->bound) return KLAB_ERR_BADARG;
+static int backward_segment(klab_engine* e, int segment, const float* dloss_dev, void* stream) {
   Ctx c{e, (hipStream_t)stream, e->cfg.dtype, e->es};
   const klab_model_cfg& cfg = e->cfg;
   const int B = e->B, d = cfg.main.d_model, inner = cfg.main.n_heads * cfg.main.d_kv, nld = cfg.main.n_dec_layers;
@@ -1002,6 +1110,20 @@ extern "C" int klab_engine_backward(klab_engine* e, int segment, const float* dl
     return swin_backward(c, e->denc, p);
   }
   return KLAB_ERR_BADARG;
+}
+
+
+extern "C" int klab_engine_backward(klab_engine* e, int segment, const float* dloss_dev, void* stream) {
+  if (!e || !e->bound || segment < 0 || segment > 2) return KLAB_ERR_BADARG;
+  int erc = 0;
+  const hipStream_t s = enter_stream(e, (hipStream_t)stream, erc);
+  if (erc) return erc;
+  if (segment == 0) {  // d(objective)/d(loss): staged at a fixed address (1.0 when the caller passes NULL)
+    if (dloss_dev) RC((int)hipMemcpyAsync(e->dloss_buf, dloss_dev, 4, hipMemcpyDeviceToDevice, s));
+    else { static const float one = 1.f; RC((int)hipMemcpyAsync(e->dloss_buf, &one, 4, hipMemcpyHostToDevice, s)); }
+  }
+  RC(run_graphed(e, 4 + segment, s, [&]() { return backward_segment(e, segment, e->dloss_buf, (void*)s); }));
+  return leave_stream(e, (hipStream_t)stream, s);
 }
 
 namespace {

@@ -654,17 +654,9 @@ __global__ __launch_bounds__(256) void klab_lmhead_gemm(GemmP p) {
 
 template <typename K>
 static int launch_kernel(K kern, const GemmP& p, int BM, int BN, size_t lds, hipStream_t s) {
-  static std::mutex mu;
-  static std::map<const void*, size_t> attr;
   {
-    std::lock_guard<std::mutex> g(mu);
-    const void* key = reinterpret_cast<const void*>(kern);
-    auto it = attr.find(key);
-    if (it == attr.end() || it->second < lds) {
-      hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return (int)e;
-      attr[key] = lds;
-    }
+    const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds);
+    if (rc) return rc;
   }
   const long tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
   hipLaunchKernelGGL(kern, dim3((unsigned)(tm * tn * p.splits)), dim3(256), lds, s, p);

@@ -4,10 +4,26 @@
 // wave-shuffle reductions; none is reshaped into a GEMM.
 #include <math.h>
 
+#include <map>
+#include <mutex>
+
 #include "common.h"
 #include "klab_mm.h"
 
 namespace klab {
+
+int ensure_dyn_lds(const void* kernel, size_t bytes) {
+  static std::mutex mu;
+  static std::map<const void*, size_t> set;
+  if (bytes > 160 * 1024) return KLAB_ERR_UNSUPPORTED;
+  std::lock_guard<std::mutex> g(mu);
+  auto it = set.find(kernel);
+  if (it != set.end() && it->second >= bytes) return KLAB_OK;
+  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return (int)e;
+  set[kernel] = bytes;
+  return KLAB_OK;
+}
 
 // ---- multi-tensor f32 -> T cast / pack ------------------------------------------------------
 // The master weights stay fp32 nn.Parameters (the reference trains in fp32, ref/train.py:25-28);

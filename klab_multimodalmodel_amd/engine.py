@@ -113,6 +113,7 @@ ENGINE_SIGS = {
                           C.POINTER(C.c_void_p), C.c_void_p], C.c_int),
     "klab_engine_forward": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_void_p], C.c_int),
     "klab_engine_backward": ([C.c_void_p, C.c_int, C.c_void_p, C.c_void_p], C.c_int),
+    "klab_engine_set_graph": ([C.c_void_p, C.c_int], C.c_int),
     "klab_engine_probe_enable": ([C.c_void_p, C.c_int], C.c_int),
     "klab_engine_probe_read": ([C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_double)], C.c_int),
     "klab_engine_loss_ptr": ([C.c_void_p], C.c_void_p),
@@ -325,6 +326,10 @@ class Engine:
     def backward(self, segment, dloss=None):
         L.check(self._lib.klab_engine_backward(self._h, segment, dloss.data_ptr() if dloss is not None else None, L.stream_ptr()),
                 "klab_engine_backward")
+
+    def set_graph(self, on=True):
+        """replay the launch sequences as hipGraphs (inputs are staged, so any input tensors may be passed)."""
+        L.check(self._lib.klab_engine_set_graph(self._h, int(on)), "klab_engine_set_graph")
 
     def probe_enable(self, on=True):
         L.check(self._lib.klab_engine_probe_enable(self._h, int(on)), "klab_engine_probe_enable")

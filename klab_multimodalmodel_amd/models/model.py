@@ -95,9 +95,8 @@ class _LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, want_grad, pixels, src, tgt, *params):
         eng = model._engine_for(pixels, src, tgt)
-        model._seed_ctr += 1
-        seed = (model._seed_base + 0x9E3779B1 * model._seed_ctr) & 0xFFFFFFFF
-        eng.forward(pixels, src, tgt, training=model.transformer.training, seed=seed, want_grad=want_grad)
+        # the engine keeps a device-side counter RNG: the base only (re)seeds it, every forward advances it
+        eng.forward(pixels, src, tgt, training=model.transformer.training, seed=model._seed_base, want_grad=want_grad)
         ctx.model = model
         ctx.eng = eng
         ctx.nparams = len(params)
@@ -209,6 +208,7 @@ class MyModel(nn.Module):
         self._views = None
         self._direct_grads = False
         self._segment_hook = None
+        self.use_graph = os.environ.get("KLAB_GRAPH", "0") == "1"  # hipGraph replay of the engine's launch sequences
         self._seed_base = torch.initial_seed() & 0xFFFFFFFF
         self._seed_ctr = 0
         self._fwd_token = 0
@@ -268,6 +268,7 @@ class MyModel(nn.Module):
                 self._flat["swin"] = torch.zeros(max(eng.grad_elems["swin"], 8), device=dev) if self.args.image_model_train else None
                 self._views = None
             eng.bind(B, Ls, Lt, tensors, self._flat["main"], self._flat["swin"], dev)
+            eng.set_graph(self.use_graph)
             self._bound_key = key
         return self._engine
 
@@ -319,7 +320,7 @@ class MyModel(nn.Module):
         try:
             for t in range(steps):
                 eng = self._engine_for(pixels, src, tgt)
-                eng.forward(pixels, src, tgt, training=False, seed=0, want_grad=False)
+                eng.forward(pixels, src, tgt, training=False, seed=self._seed_base, want_grad=False)
                 logits = eng.buffer("logits").view(B, steps, -1)[:, t].float()
                 nxt = logits.argmax(-1)
                 nxt = torch.where(done, torch.full_like(nxt, cfg.pad_token_id), nxt)
