@@ -346,7 +346,8 @@ __global__ __launch_bounds__(256) void dbias_reduce_kernel(const bf16_t* __restr
   const long row = idx / Lk;
   const int k = idx % Lk;
   float a = 0.f;
-  for (int b = 0; b < B; ++b) a += (float)ds[((long)b * HLq + row) * Lkp + k];
+#pragma unroll 16
+  for (int b = 0; b < B; ++b) a += (float)ds[((long)b * HLq + row) * Lkp + k];  // independent loads: keep many in flight
   dbias[idx] += a;
 }
 

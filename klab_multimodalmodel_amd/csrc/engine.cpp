@@ -97,7 +97,9 @@ struct klab_engine {
   std::vector<const float*> W[3];
   float* G[3] = {nullptr, nullptr, nullptr};
   void* warena = nullptr; float* farena = nullptr;
-  void* cast_desc = nullptr; int n_cast = 0; long cast_total4 = 0;
+  void* cast_desc = nullptr; int n_cast = 0; long cast_total4 = 0;      // trainable GEMM weights (cast every forward)
+  void* cast_desc_frozen = nullptr; int n_cast_frozen = 0; long cast_total4_frozen = 0;  // frozen towers (cast when dirty)
+  bool frozen_valid = false;  // arena copies + CPB bias tables of the frozen towers are up to date
   void* fcast_desc = nullptr; int n_fcast = 0; long fcast_total4 = 0;
   uint32_t* seed_dev = nullptr; int* err_dev = nullptr;
   const int *enc_bucket = nullptr, *dec_bucket = nullptr, *lang_bucket = nullptr;
@@ -383,7 +385,7 @@ size_t plan_workspace(klab_engine* e, void* base, int B, int Ls, int Lt) {
   e->tgt_buf = (long long*)b.take((size_t)B * Lt * 8);
   e->warena = b.take((size_t)e->warena_elems * es);
   e->farena = (float*)b.take((size_t)e->farena_elems * 4);
-  e->cast_desc = b.take(sizeof(long) * 3 * (e->P[0].size() + e->P[1].size() + e->P[2].size() + 1));
+  e->cast_desc = b.take(sizeof(long) * 3 * 2 * (e->P[0].size() + e->P[1].size() + e->P[2].size() + 1));  // two groups
   e->fcast_desc = b.take(sizeof(long) * 3 * (e->P[0].size() + 1));
 
   plan_t5_stack(b, c.lang, c.lang.n_layers, false, false, B * Ls, B, Ls, es, e->lang, 0);
@@ -667,7 +669,7 @@ int t5_stack_backward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Pa
 // ------------------------------------------------------------------------------------------------
 // Swin-V2 forward (HF/swinv2:917-958, eval mode always: SURVEY §0.4)
 // ------------------------------------------------------------------------------------------------
-int swin_forward(const Ctx& c, const float* pixels, float p_in) {
+int swin_forward(const Ctx& c, const float* pixels, float p_in, bool refresh_bias) {
   klab_engine* e = c.e;
   const klab_swin_cfg& s = e->cfg.swin;
   const auto& P = e->P[0];
@@ -688,8 +690,9 @@ int swin_forward(const Ctx& c, const float* pixels, float p_in) {
       const SwinBlockIdx& ix = e->si.st[st].blk[k];
       const int C = q.C, M = (int)q.M, F = s.mlp_ratio * C, n = q.w * q.w;
       q.x_in = x; q.xt_in = xt;
-      RC(klab_swin_cpb_bias(e->swin_coords[st], e->swin_index[st], W[ix.c0w], W[ix.c0b], W[ix.c2w], q.table, q.hidden, q.bias,
-                            e->swin_ntab[st], n, q.H, 512, c.ws()));
+      if (refresh_bias)  // input-independent: with a frozen Swin the 16*sigmoid(CPB) tables are computed once per weight version
+        RC(klab_swin_cpb_bias(e->swin_coords[st], e->swin_index[st], W[ix.c0w], W[ix.c0b], W[ix.c2w], q.table, q.hidden, q.bias,
+                              e->swin_ntab[st], n, q.H, 512, c.ws()));
       const float* qkvb = ix.qb >= 0 ? e->farena + bias_off : nullptr;
       bias_off += 3 * C;
       RC(linear_fwd(c, xt, M, C, P[ix.qw].warena_off, 3 * C, q.qkv, 3 * C, c.dt, qkvb));
@@ -832,10 +835,12 @@ extern "C" int klab_engine_bind(klab_engine* e, int B, int Ls, int Lt, void* wor
   }
   // cast descriptors: {src, dst_off, n4_prefix}
   hipStream_t hs = (hipStream_t)stream;
-  {
+  for (int grp = 0; grp < 2; ++grp) {  // 0: trainable (main, and Swin when --image_model_train), 1: frozen (lang, frozen Swin)
     std::vector<long> d;
     long pre = 0; int n = 0;
-    for (int m = 0; m < 3; ++m)
+    for (int m = 0; m < 3; ++m) {
+      const bool frozen = (m == 1) || (m == 0 && !e->cfg.train_swin);
+      if (frozen != (grp == 1)) continue;
       for (size_t i = 0; i < e->P[m].size(); ++i) {
         const ParamInfo& p = e->P[m][i];
         if (p.warena_off < 0) continue;
@@ -843,12 +848,18 @@ extern "C" int klab_engine_bind(klab_engine* e, int B, int Ls, int Lt, void* wor
         d.push_back((long)e->W[m][i]); d.push_back(p.warena_off); d.push_back(pre);
         pre += p.numel / 4; ++n;
       }
+    }
+    void* dst = grp == 0 ? e->cast_desc : (void*)((char*)e->cast_desc + sizeof(long) * 3 * e->P[2].size() + sizeof(long) * 3 * e->P[0].size());
+    if (grp == 1) { e->cast_desc_frozen = dst; e->n_cast_frozen = n; e->cast_total4_frozen = pre; }
+    if (n == 0) { if (grp == 0) { e->n_cast = 0; e->cast_total4 = 0; } continue; }
+    hipError_t er0 = hipMemcpyAsync(dst, d.data(), d.size() * sizeof(long), hipMemcpyHostToDevice, hs);
+    if (er0 != hipSuccess) return (int)er0;
+    er0 = hipStreamSynchronize(hs);  // bind time only (d goes out of scope)
+    if (er0 != hipSuccess) return (int)er0;
+    if (grp == 1) continue;
     e->n_cast = n; e->cast_total4 = pre;
-    hipError_t er = hipMemcpyAsync(e->cast_desc, d.data(), d.size() * sizeof(long), hipMemcpyHostToDevice, hs);
-    if (er != hipSuccess) return (int)er;
-    er = hipStreamSynchronize(hs);  // bind time only (d goes out of scope)
-    if (er != hipSuccess) return (int)er;
   }
+  e->frozen_valid = false;
   {
     std::vector<long> d;
     long pre = 0; int n = 0;
@@ -935,22 +946,26 @@ int run_graphed(klab_engine* e, int slot, hipStream_t s, F body) {
 }
 
 // everything of the forward before the LM head (inputs are the engine-owned staged copies)
-int forward_part_a(klab_engine* e, hipStream_t stream, float p) {
+int forward_part_a(klab_engine* e, hipStream_t stream, float p, bool refresh_frozen) {
   Ctx c{e, stream, e->cfg.dtype, e->es};
   const klab_model_cfg& cfg = e->cfg;
   const float* pixels = e->pixels_buf;
   const long long *src_ids = e->src_buf, *tgt_ids = e->tgt_buf;
   hipLaunchKernelGGL(seed_step_kernel, dim3(1), dim3(1), 0, c.s, e->seed_dev);
   // 1. weights: fp32 masters -> compute-dtype arena (+ fused f32 bias vectors)
-  RC(klab_cast_pack(e->cast_desc, e->n_cast, e->cast_total4, e->warena, c.dt, c.ws()));
-  if (e->n_fcast) RC(klab_cast_pack(e->fcast_desc, e->n_fcast, e->fcast_total4, e->farena, KLAB_F32, c.ws()));
+  if (e->n_cast) RC(klab_cast_pack(e->cast_desc, e->n_cast, e->cast_total4, e->warena, c.dt, c.ws()));
+  if (refresh_frozen || e->cfg.train_swin) {
+    if (refresh_frozen && e->n_cast_frozen)
+      RC(klab_cast_pack(e->cast_desc_frozen, e->n_cast_frozen, e->cast_total4_frozen, e->warena, c.dt, c.ws()));
+    if (e->n_fcast) RC(klab_cast_pack(e->fcast_desc, e->n_fcast, e->fcast_total4, e->farena, KLAB_F32, c.ws()));
+  }
   const int B = e->B, d = cfg.main.d_model;
   // 2./3. The two towers are independent until the concat.  Swin-V2 (ref/models/model.py:22, rows [0, N_img)) is
   //    enqueued FIRST on the main stream -- its launches are long, so the host runs far ahead -- and the frozen
   //    language encoder (model.py:20-21, rows [N_img, Le); ~100 launches of ~5 us over 576 tokens, which would
   //    otherwise be paced by the host) is then enqueued on the side stream and runs underneath it.
   RC((int)hipEventRecord(e->ev_fork, c.s));
-  RC(swin_forward(c, pixels, p));
+  RC(swin_forward(c, pixels, p, refresh_frozen || e->cfg.train_swin));
   RC((int)hipStreamWaitEvent(e->side, e->ev_fork, 0));
   {
     Ctx cs{e, e->side, e->cfg.dtype, e->es};
@@ -990,7 +1005,10 @@ extern "C" int klab_engine_forward(klab_engine* e, const float* pixels, const lo
   if (erc) return erc;
   Ctx c{e, xs, e->cfg.dtype, e->es};
   const klab_model_cfg& cfg = e->cfg;
-  const float p = training ? cfg.main.dropout : 0.f;
+  // `training` bit 0: T5 dropout on; bit 1: the caller vouches that the frozen towers' weights are unchanged since the
+  // previous forward of this binding (skip their re-cast and the Swin CPB tables)
+  const float p = (training & 1) ? cfg.main.dropout : 0.f;
+  const bool refresh_frozen = !((training & 2) && e->frozen_valid);
   e->p_train = p;
   e->last_tgt = e->tgt_buf;
   // stage the inputs (device-to-device, stream-ordered): replayed graphs read fixed addresses
@@ -1003,7 +1021,12 @@ extern "C" int klab_engine_forward(klab_engine* e, const float* pixels, const lo
     hipLaunchKernelGGL(seed_set_kernel, dim3(1), dim3(1), 0, c.s, e->seed_dev, seed);
     e->seed_base = seed; e->seed_set = true;
   }
-  RC(run_graphed(e, training ? 1 : 0, c.s, [&]() { return forward_part_a(e, c.s, p); }));
+  if (refresh_frozen) {  // not worth a graph slot: happens once per weight version
+    RC(forward_part_a(e, c.s, p, true));
+    e->frozen_valid = true;
+  } else {
+    RC(run_graphed(e, (training & 1) ? 1 : 0, c.s, [&]() { return forward_part_a(e, c.s, p, false); }));
+  }
   {
     const int Md = B * e->Lt, V = cfg.main.vocab;
     klab_gemm_args g = G0(c, Md, V, d, e->dec.out_t, d, 1, woff(c, e->P[2][e->mi.shared].warena_off), d, 1, e->logits, V, c.dt);

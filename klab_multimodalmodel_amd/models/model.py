@@ -96,7 +96,8 @@ class _LossFn(torch.autograd.Function):
     def forward(ctx, model, want_grad, pixels, src, tgt, *params):
         eng = model._engine_for(pixels, src, tgt)
         # the engine keeps a device-side counter RNG: the base only (re)seeds it, every forward advances it
-        eng.forward(pixels, src, tgt, training=model.transformer.training, seed=model._seed_base, want_grad=want_grad)
+        eng.forward(pixels, src, tgt, training=int(model.transformer.training) | (2 if model._frozen_unchanged() else 0),
+                    seed=model._seed_base, want_grad=want_grad)
         ctx.model = model
         ctx.eng = eng
         ctx.nparams = len(params)
@@ -211,6 +212,7 @@ class MyModel(nn.Module):
         self.use_graph = os.environ.get("KLAB_GRAPH", "0") == "1"  # hipGraph replay of the engine's launch sequences
         self._seed_base = torch.initial_seed() & 0xFFFFFFFF
         self._seed_ctr = 0
+        self._frozen_fp = None
         self._fwd_token = 0
 
     # ---- weights -----------------------------------------------------------------------------
@@ -270,7 +272,19 @@ class MyModel(nn.Module):
             eng.bind(B, Ls, Lt, tensors, self._flat["main"], self._flat["swin"], dev)
             eng.set_graph(self.use_graph)
             self._bound_key = key
+            self._frozen_fp = None
         return self._engine
+
+    def _frozen_unchanged(self):
+        """True when no frozen-tower parameter was written since the previous forward (tensor version counters):
+        the engine may then keep its bf16 copies and the Swin position-bias tables."""
+        ps = list(self.language_model.parameters())
+        if not self.args.image_model_train:
+            ps += list(self.image_model.parameters())
+        fp = sum(p._version for p in ps)
+        same = fp == self._frozen_fp
+        self._frozen_fp = fp
+        return same
 
     def _grad_targets(self):
         if self._views is None:

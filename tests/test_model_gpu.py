@@ -277,3 +277,24 @@ def test_hipgraph_replay_matches_eager():
         ls.append(loss.item())
         m.zero_grad(set_to_none=True)
     assert len(set(ls)) == 5
+
+
+def test_frozen_tower_caches_follow_weight_updates():
+    """the engine keeps bf16 copies / CPB tables of the frozen towers across steps; an in-place weight change
+    (load_state_dict, manual edit) must invalidate them through the tensors' version counters."""
+    m, g = build("tiny_a", torch.float32, False)
+    m.transformer.eval()
+    with torch.no_grad():
+        l1 = run(m, g).item()
+        l2 = run(m, g).item()  # cached path
+        assert l1 == l2
+        m.language_model.get_parameter("encoder.block.0.layer.0.SelfAttention.q.weight").mul_(1.5)
+        l3 = run(m, g).item()
+        assert abs(l3 - l1) > 1e-6
+        sd = m.image_model.state_dict()
+        sd["encoder.layers.0.blocks.0.attention.self.continuous_position_bias_mlp.2.weight"] = \
+            sd["encoder.layers.0.blocks.0.attention.self.continuous_position_bias_mlp.2.weight"] * -2.0
+        m.image_model.load_state_dict(sd)
+        l4 = run(m, g).item()
+        assert abs(l4 - l3) > 1e-7
+        assert run(m, g).item() == l4
