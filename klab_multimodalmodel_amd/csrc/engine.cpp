@@ -109,7 +109,11 @@ struct klab_engine {
   void* kv_all = nullptr; void* dkv_all = nullptr;
   void* logits = nullptr; float *loss_row = nullptr, *inv_n = nullptr, *loss = nullptr;
   float *dh_a = nullptr, *dh_b = nullptr, *dxn = nullptr, *denc = nullptr;
-  void *dy_t = nullptr, *dctx = nullptr, *dqkv = nullptr, *dhmid = nullptr, *dqc = nullptr, *ds_ws = nullptr;
+  void *dctx = nullptr, *ds_ws = nullptr;
+  // per-sub-layer gradient operands (no buffer is rewritten inside a backward segment, so the weight-gradient GEMMs
+  // can trail on the side stream with read-after-write events only)
+  std::vector<void*> dy_pool, dhmid_pool, dqkv_pool, dqc_pool;
+  std::vector<hipEvent_t> evpool; int ev_next = 0;
   void *cols = nullptr, *pe_out = nullptr; float *pe_mean = nullptr, *pe_rstd = nullptr; float* x0 = nullptr; void* x0t = nullptr;
   std::vector<SwinStageBufs> sw;
   float *sw_fmean = nullptr, *sw_frstd = nullptr;
@@ -400,11 +404,16 @@ size_t plan_workspace(klab_engine* e, void* base, int B, int Ls, int Lt) {
   e->dh_b = (float*)b.take((size_t)Mx * d * 4);
   e->dxn = (float*)b.take((size_t)Mx * d * 4);
   e->denc = (float*)b.take((size_t)Me * d * 4);
-  e->dy_t = b.take((size_t)Mx * d * es);
+  {
+    const int nl = c.main.n_layers > c.main.n_dec_layers ? c.main.n_layers : c.main.n_dec_layers;
+    e->dy_pool.assign(3 * nl + 2, nullptr); e->dhmid_pool.assign(nl, nullptr); e->dqkv_pool.assign(nl, nullptr);
+    e->dqc_pool.assign(c.main.n_dec_layers, nullptr);
+    for (auto& q : e->dy_pool) q = b.take((size_t)Mx * d * es);
+    for (auto& q : e->dhmid_pool) q = b.take((size_t)Mx * ff * es);
+    for (auto& q : e->dqkv_pool) q = b.take((size_t)Mx * 3 * inner * es);
+    for (auto& q : e->dqc_pool) q = b.take((size_t)Md * inner * es);
+  }
   e->dctx = b.take((size_t)Mx * inner * es);
-  e->dqkv = b.take((size_t)Mx * 3 * inner * es);
-  e->dhmid = b.take((size_t)Mx * ff * es);
-  e->dqc = b.take((size_t)Md * inner * es);
   {
     const long Lmax = Le > Lt ? Le : Lt;
     e->ds_ws = b.take((size_t)B * c.main.n_heads * Lmax * ((Lmax + 31) & ~31L) * es);
@@ -578,7 +587,31 @@ int t5_stack_forward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Par
 }
 
 // ------------------------------------------------------------------------------------------------
+// side-stream helpers: "everything enqueued on the main stream so far" -> visible to the side stream, and back
+// ------------------------------------------------------------------------------------------------
+int side_after_main(const Ctx& c) {
+  klab_engine* e = c.e;
+  hipEvent_t ev = e->evpool[e->ev_next++ % e->evpool.size()];
+  RC((int)hipEventRecord(ev, c.s));
+  return (int)hipStreamWaitEvent(e->side, ev, 0);
+}
+int main_after_side(const Ctx& c) {
+  klab_engine* e = c.e;
+  hipEvent_t ev = e->evpool[e->ev_next++ % e->evpool.size()];
+  RC((int)hipEventRecord(ev, e->side));
+  return (int)hipStreamWaitEvent(c.s, ev, 0);
+}
+// weight gradient on the side stream: its operands were produced on the main stream just before this call
+int wgrad_side(const Ctx& c, const void* dy, long lddy, const void* x, long ldx, int M, int N, int K, float* dw) {
+  RC(side_after_main(c));
+  Ctx cs{c.e, c.e->side, c.dt, c.es};
+  return linear_wgrad(cs, dy, lddy, x, ldx, M, N, K, dw);
+}
+
+// ------------------------------------------------------------------------------------------------
 // T5 stack backward.  In: dxn = d loss / d (final-norm output) in f32 [M,d].  Out: dh_cur = d loss / d h[0].
+// The activation-gradient chain (dgrad GEMMs, attention, norms) runs on the main stream; every weight gradient is
+// issued to the side stream as soon as its two operands exist, so the two families of small GEMMs overlap.
 // ------------------------------------------------------------------------------------------------
 int t5_stack_backward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<ParamInfo>& P, const std::vector<const float*>& W,
                       float* Gflat, const std::vector<T5LayerIdx>& L, int final_ln, T5StackBufs& s, bool dec, int stack_id, float p,
@@ -592,33 +625,40 @@ int t5_stack_backward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Pa
   float* dh_oth = e->dh_b;
   auto G = [&](int pi) { return Gflat + P[pi].grad_off; };
   const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  int dy_i = 0;
+  auto next_dy = [&]() { return e->dy_pool[dy_i++ % e->dy_pool.size()]; };
   RC(hipMemsetAsync(s.dbias, 0, (size_t)H * Lq * Lq * 4, c.s));
   // final norm: y = drop(norm(h[j])); previous sub-layer output dropout = FFN_OUT of the last layer
-  RC(klab_rmsnorm_bwd(e->dxn, s.h[j], W[final_ln], s.rstd_f, nullptr, dh_cur, e->dy_t, c.dt, G(final_ln), M, d, 0, 0, 0, p,
+  void* dy = next_dy();  // masked, compute-dtype gradient of the current sub-layer's GEMM output
+  RC(klab_rmsnorm_bwd(e->dxn, s.h[j], W[final_ln], s.rstd_f, nullptr, dh_cur, dy, c.dt, G(final_ln), M, d, 0, 0, 0, p,
                       tag_of(stack_id, 0, SITE_FINAL), p, tag_of(stack_id, (int)L.size() - 1, SITE_FFN_OUT), e->seed_dev, c.ws()));
   for (int i = (int)L.size() - 1; i >= 0; --i) {
     const T5LayerIdx& l = L[i];
     T5LayerBufs& b = s.L[i];
+    void* dhmid = e->dhmid_pool[i];
+    void* dqkv = e->dqkv_pool[i];
     // ---------------- FFN ----------------
     --j;
-    RC(linear_wgrad(c, e->dy_t, d, b.hmid, ff, M, d, ff, G(l.wo)));
+    RC(wgrad_side(c, dy, d, b.hmid, ff, M, d, ff, G(l.wo)));
     {
-      klab_gemm_args g = G0(c, M, ff, d, e->dy_t, d, 1, woff(c, P[l.wo].warena_off), ff, 0, e->dhmid, ff, c.dt);
+      klab_gemm_args g = G0(c, M, ff, d, dy, d, 1, woff(c, P[l.wo].warena_off), ff, 0, dhmid, ff, c.dt);
       g.aux = b.hmid; g.ldaux = ff; g.aux_mode = KLAB_AUX_NONZERO; g.aux_scale = inv_keep;
       RC(klab_gemm(&g, c.ws()));
     }
-    RC(linear_wgrad(c, e->dhmid, ff, b.xn3, d, M, ff, d, G(l.wi)));
-    RC(linear_dgrad(c, e->dhmid, ff, M, ff, P[l.wi].warena_off, d, e->dxn, KLAB_F32));
+    RC(wgrad_side(c, dhmid, ff, b.xn3, d, M, ff, d, G(l.wi)));
+    RC(linear_dgrad(c, dhmid, ff, M, ff, P[l.wi].warena_off, d, e->dxn, KLAB_F32));
     {
       const uint32_t tprev = dec ? tag_of(stack_id, i, SITE_XOUT) : tag_of(stack_id, i, SITE_ATTN_OUT);
-      RC(klab_rmsnorm_bwd(e->dxn, s.h[j], W[l.ln2], b.rstd3, dh_cur, dh_oth, e->dy_t, c.dt, G(l.ln2), M, d, 0, 0, 0, 0.f, 0, p, tprev,
+      dy = next_dy();
+      RC(klab_rmsnorm_bwd(e->dxn, s.h[j], W[l.ln2], b.rstd3, dh_cur, dh_oth, dy, c.dt, G(l.ln2), M, d, 0, 0, 0, 0.f, 0, p, tprev,
                           e->seed_dev, c.ws()));
       float* t = dh_cur; dh_cur = dh_oth; dh_oth = t;
     }
     if (dec) {  // ---------------- cross attention ----------------
       --j;
-      RC(linear_wgrad(c, e->dy_t, d, b.ctx2, inner, M, d, inner, G(l.co)));
-      RC(linear_dgrad(c, e->dy_t, d, M, d, P[l.co].warena_off, inner, e->dctx, c.dt));
+      void* dqc = e->dqc_pool[i];
+      RC(wgrad_side(c, dy, d, b.ctx2, inner, M, d, inner, G(l.co)));
+      RC(linear_dgrad(c, dy, d, M, d, P[l.co].warena_off, inner, e->dctx, c.dt));
       klab_attn_args a;
       memset(&a, 0, sizeof(a));
       a.dtype = c.dt; a.q = b.qc; a.ldq = inner;
@@ -626,20 +666,21 @@ int t5_stack_backward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Pa
       a.v = eoff(c, (void*)kv_all, (long)i * 2 * inner + inner); a.ldv = kv_ld;
       a.ctx = b.ctx2; a.ldo = inner; a.lse = b.lse2; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lkv; a.dk = dk;
       a.drop_p = p; a.seed_dev = e->seed_dev; a.drop_tag = tag_of(stack_id, i, SITE_XPROB);
-      a.dctx = e->dctx; a.lddo = inner; a.dq = e->dqc; a.lddq = inner;
+      a.dctx = e->dctx; a.lddo = inner; a.dq = dqc; a.lddq = inner;
       a.dk_out = eoff(c, dkv_all, (long)i * 2 * inner); a.lddk = kv_ld;
       a.dv = eoff(c, dkv_all, (long)i * 2 * inner + inner); a.lddv = kv_ld;
       RC(klab_t5_attn_bwd(&a, c.ws()));
-      RC(linear_wgrad(c, e->dqc, inner, b.xn2, d, M, inner, d, G(l.cq)));
-      RC(linear_dgrad(c, e->dqc, inner, M, inner, P[l.cq].warena_off, d, e->dxn, KLAB_F32));
-      RC(klab_rmsnorm_bwd(e->dxn, s.h[j], W[l.ln1], b.rstd2, dh_cur, dh_oth, e->dy_t, c.dt, G(l.ln1), M, d, 0, 0, 0, 0.f, 0, p,
+      RC(wgrad_side(c, dqc, inner, b.xn2, d, M, inner, d, G(l.cq)));
+      RC(linear_dgrad(c, dqc, inner, M, inner, P[l.cq].warena_off, d, e->dxn, KLAB_F32));
+      dy = next_dy();
+      RC(klab_rmsnorm_bwd(e->dxn, s.h[j], W[l.ln1], b.rstd2, dh_cur, dh_oth, dy, c.dt, G(l.ln1), M, d, 0, 0, 0, 0.f, 0, p,
                           tag_of(stack_id, i, SITE_ATTN_OUT), e->seed_dev, c.ws()));
       float* t = dh_cur; dh_cur = dh_oth; dh_oth = t;
     }
     // ---------------- self attention ----------------
     --j;
-    RC(linear_wgrad(c, e->dy_t, d, b.ctx, inner, M, d, inner, G(l.o)));
-    RC(linear_dgrad(c, e->dy_t, d, M, d, P[l.o].warena_off, inner, e->dctx, c.dt));
+    RC(wgrad_side(c, dy, d, b.ctx, inner, M, d, inner, G(l.o)));
+    RC(linear_dgrad(c, dy, d, M, d, P[l.o].warena_off, inner, e->dctx, c.dt));
     {
       klab_attn_args a;
       memset(&a, 0, sizeof(a));
@@ -647,16 +688,17 @@ int t5_stack_backward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Pa
       a.v = eoff(c, b.qkv, 2 * inner); a.ldv = 3 * inner; a.bias = s.bias; a.causal = dec ? 1 : 0;
       a.ctx = b.ctx; a.ldo = inner; a.lse = b.lse; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lq; a.dk = dk;
       a.drop_p = p; a.seed_dev = e->seed_dev; a.drop_tag = tag_of(stack_id, i, SITE_PROB);
-      a.dctx = e->dctx; a.lddo = inner; a.dq = e->dqkv; a.lddq = 3 * inner;
-      a.dk_out = eoff(c, e->dqkv, inner); a.lddk = 3 * inner; a.dv = eoff(c, e->dqkv, 2 * inner); a.lddv = 3 * inner;
+      a.dctx = e->dctx; a.lddo = inner; a.dq = dqkv; a.lddq = 3 * inner;
+      a.dk_out = eoff(c, dqkv, inner); a.lddk = 3 * inner; a.dv = eoff(c, dqkv, 2 * inner); a.lddv = 3 * inner;
       a.dbias = s.dbias; a.ds_ws = e->ds_ws;
       RC(klab_t5_attn_bwd(&a, c.ws()));
     }
-    RC(linear_wgrad(c, e->dqkv, 3 * inner, b.xn1, d, M, 3 * inner, d, G(l.q)));  // q|k|v grads are adjacent
-    RC(linear_dgrad(c, e->dqkv, 3 * inner, M, 3 * inner, P[l.q].warena_off, d, e->dxn, KLAB_F32));
+    RC(wgrad_side(c, dqkv, 3 * inner, b.xn1, d, M, 3 * inner, d, G(l.q)));  // q|k|v grads are adjacent
+    RC(linear_dgrad(c, dqkv, 3 * inner, M, 3 * inner, P[l.q].warena_off, d, e->dxn, KLAB_F32));
     {
       const bool first = (i == 0);
-      RC(klab_rmsnorm_bwd(e->dxn, s.h[j], W[l.ln0], b.rstd1, dh_cur, dh_oth, first ? nullptr : e->dy_t, c.dt, G(l.ln0), M, d, 0, 0, 0, 0.f, 0,
+      if (!first) dy = next_dy();
+      RC(klab_rmsnorm_bwd(e->dxn, s.h[j], W[l.ln0], b.rstd1, dh_cur, dh_oth, first ? nullptr : dy, c.dt, G(l.ln0), M, d, 0, 0, 0, 0.f, 0,
                           first ? 0.f : p, first ? 0u : tag_of(stack_id, i - 1, SITE_FFN_OUT), e->seed_dev, c.ws()));
       float* t = dh_cur; dh_cur = dh_oth; dh_oth = t;
     }
@@ -767,6 +809,7 @@ extern "C" void klab_engine_destroy(klab_engine* e) {
   if (e->ev_out) hipEventDestroy(e->ev_out);
   if (e->own) hipStreamDestroy(e->own);
   for (auto& g : e->gs) if (g.exec) hipGraphExecDestroy(g.exec);
+  for (auto ev : e->evpool) hipEventDestroy(ev);
   for (auto ev : e->ev0) hipEventDestroy(ev);
   for (auto ev : e->ev1) hipEventDestroy(ev);
   delete e;
@@ -890,6 +933,8 @@ extern "C" int klab_engine_bind(klab_engine* e, int B, int Ls, int Lt, void* wor
     RC((int)hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     RC((int)hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     RC((int)hipStreamCreateWithFlags(&e->own, hipStreamNonBlocking));
+    e->evpool.resize(256);
+    for (auto& ev : e->evpool) RC((int)hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     RC((int)hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
     RC((int)hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming));
   }
@@ -1092,32 +1137,38 @@ static int backward_segment(klab_engine* e, int segment, const float* dloss_dev,
   const float p = e->p_train;
   float* Gm = e->G[2];
   if (segment == 0) {
+    e->ev_next = 0;
     RC((int)hipMemsetAsync(Gm + e->seg_off[0], 0, (size_t)e->seg_len[0] * 4, c.s));
     const int Md = B * e->Lt, V = cfg.main.vocab;
     const float alpha = cfg.main.scale_decoder_outputs ? 1.f / sqrtf((float)d) : 1.f;
+    Ctx cs{e, e->side, c.dt, c.es};
+    RC(side_after_main(c));
+    {  // d shared [V,d] = dlogits^T @ dec_out  (first of the tied weight's three contributors) -- side stream
+      klab_gemm_args g = G0(cs, V, d, Md, e->logits, V, 0, e->dec.out_t, d, 0, Gm + e->P[2][e->mi.shared].grad_off, d, KLAB_F32);
+      g.alpha = alpha; g.alpha_dev = dloss_dev; g.accumulate = 1; g.atomic_ok = 1;
+      RC(klab_gemm(&g, cs.ws()));
+    }
     {  // d(dec_out) [Md,d] = dlogits [Md,V] @ shared [V,d]
       klab_gemm_args g = G0(c, Md, d, V, e->logits, V, 1, woff(c, e->P[2][e->mi.shared].warena_off), d, 0, e->dxn, d, KLAB_F32);
       g.alpha = alpha; g.alpha_dev = dloss_dev;
       RC(klab_gemm(&g, c.ws()));
     }
-    {  // d shared [V,d] = dlogits^T @ dec_out  (first of the tied weight's three contributors)
-      klab_gemm_args g = G0(c, V, d, Md, e->logits, V, 0, e->dec.out_t, d, 0, Gm + e->P[2][e->mi.shared].grad_off, d, KLAB_F32);
-      g.alpha = alpha; g.alpha_dev = dloss_dev; g.accumulate = 1; g.atomic_ok = 1;
-      RC(klab_gemm(&g, c.ws()));
-    }
     float* dh0 = nullptr;
     RC(t5_stack_backward(c, cfg.main, e->P[2], e->W[2], Gm, e->mi.dec, e->mi.dec_final, e->dec, true, STACK_DEC, p, B, e->kv_all, e->dkv_all,
                          e->Le, (long)nld * 2 * inner, &dh0));
-    // decoder input embedding: scatter-add into the tied table (second contributor)
+    // decoder input embedding: scatter-add into the tied table (second contributor); on the side stream BEHIND the
+    // LM-head weight gradient, which read-modify-writes the same rows non-atomically
+    RC(side_after_main(c));
     RC(klab_embed_bwd(e->last_tgt, 1, e->Lt, cfg.main.start_id, cfg.main.pad_id, dh0, Gm + e->P[2][e->mi.shared].grad_off, V, Md, d, p,
-                      e->seed_dev, tag_of(STACK_DEC, 0, SITE_IN), c.ws()));
-    // cross-attention K/V projections of all layers at once: weights + d(encoder output)
+                      e->seed_dev, tag_of(STACK_DEC, 0, SITE_IN), cs.ws()));
+    // cross-attention K/V projections of all layers at once: weights (side) + d(encoder output) (main)
     const int Me = B * e->Le, Nkv = nld * 2 * inner;
-    RC(linear_wgrad(c, e->dkv_all, Nkv, e->enc.out_t, d, Me, Nkv, d, Gm + e->kvall_g_off));
+    RC(linear_wgrad(cs, e->dkv_all, Nkv, e->enc.out_t, d, Me, Nkv, d, Gm + e->kvall_g_off));
     RC(linear_dgrad(c, e->dkv_all, Nkv, Me, Nkv, e->kvall_w_off, d, e->denc, KLAB_F32));
-    return 0;
+    return main_after_side(c);  // the segment's gradient slice is final for the caller's stream
   }
   if (segment == 1) {
+    e->ev_next = 0;
     RC((int)hipMemsetAsync(Gm + e->seg_off[1], 0, (size_t)e->seg_len[1] * 4, c.s));
     // the stack consumes dxn as d(final-norm output)
     const int Me = B * e->Le;
@@ -1126,7 +1177,7 @@ static int backward_segment(klab_engine* e, int segment, const float* dloss_dev,
     RC(t5_stack_backward(c, cfg.main, e->P[2], e->W[2], Gm, e->mi.enc, e->mi.enc_final, e->enc, false, STACK_ENC, p, B, nullptr, nullptr, 0, 0,
                          &dh0));
     if (cfg.train_swin) RC((int)hipMemcpyAsync(e->denc, dh0, (size_t)Me * d * 4, hipMemcpyDeviceToDevice, c.s));
-    return 0;
+    return main_after_side(c);
   }
   if (segment == 2) {
     if (!cfg.train_swin) return 0;
