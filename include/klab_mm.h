@@ -114,9 +114,12 @@ typedef struct klab_attn_args {
   float* dbias;
   void* ds_ws; /* optional scratch [B,H,Lq,roundup(Lk,32)] in `dtype`: with it the position-bias gradient is a
                   deterministic batch reduction of stored dS instead of 64-way contended float atomics */
+  int ds_defer; /* 1: only store dS; the caller reduces several layers' scratch at once with klab_dbias_reduce */
 } klab_attn_args;
 int klab_t5_attn_fwd(const klab_attn_args* a, void* stream);
 int klab_t5_attn_bwd(const klab_attn_args* a, void* stream);
+/* dbias[H,Lq,Lk] += sum over nbatch slabs of ds_ws [nbatch, H, Lq, roundup(Lk,32)] (bf16), in a fixed order */
+int klab_dbias_reduce(const void* ds_ws, int dtype, float* dbias, int nbatch, int H, int Lq, int Lk, void* stream);
 
 /* ---- Swin-V2 shifted-window cosine attention (HF/swinv2:389-455 + roll/partition/mask/reverse of
  * :652-705, :146-166, :620-643) -- one call per block.  qkv [B*R*R, 3C], ctx [B*R*R, C] (`dtype`),

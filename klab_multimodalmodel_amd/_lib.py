@@ -33,7 +33,7 @@ class AttnArgs(C.Structure):
                 ("B", i32), ("H", i32), ("Lq", i32), ("Lk", i32), ("dk", i32),
                 ("drop_p", f32), ("seed_dev", vp), ("drop_tag", u32),
                 ("dctx", vp), ("lddo", i64), ("dq", vp), ("lddq", i64), ("dk_out", vp), ("lddk", i64),
-                ("dv", vp), ("lddv", i64), ("dbias", vp), ("ds_ws", vp)]
+                ("dv", vp), ("lddv", i64), ("dbias", vp), ("ds_ws", vp), ("ds_defer", i32)]
 
 
 class SwinAttnArgs(C.Structure):
@@ -52,6 +52,7 @@ SIGNATURES = {
     "klab_layernorm_bwd": [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, u32, vp],
     "klab_t5_attn_fwd": [C.POINTER(AttnArgs), vp],
     "klab_t5_attn_bwd": [C.POINTER(AttnArgs), vp],
+    "klab_dbias_reduce": [vp, i32, vp, i32, i32, i32, i32, vp],
     "klab_swin_attn_fwd": [C.POINTER(SwinAttnArgs), vp],
     "klab_swin_attn_bwd": [C.POINTER(SwinAttnArgs), vp],
     "klab_swin_cpb_bias": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void t5_attn_fwd_kernel(AttnP p) {
   }
   __syncthreads();
 
-  const DropCtx dc = make_drop(p.seed, p.tag, p.p);
+  const DropCtx dc = drop_slab(make_drop(p.seed, p.tag, p.p), (uint32_t)(b * p.H + h));
   for (int i = wave; i < TQ; i += 4) {
     const int qi = q0 + i;
     if (qi >= Lq) continue;
@@ -114,8 +114,8 @@ __global__ __launch_bounds__(256) void t5_attn_fwd_kernel(AttnP p) {
     sum = wave_sum(sum);
     const float inv = 1.f / sum;
     if (lane == 0 && p.lse) p.lse[((long)b * p.H + h) * Lq + qi] = m + __logf(sum);
-    const uint64_t base = (((uint64_t)b * p.H + h) * Lq + qi) * (uint64_t)Lk;
-    for (int j = lane; j < Lk; j += 64) Ps[i * pst + j] = __expf(Ps[i * pst + j] - m) * inv * drop_mult(dc, base + j);
+    const uint32_t base = (uint32_t)qi * (uint32_t)Lk;
+    for (int j = lane; j < Lk; j += 64) Ps[i * pst + j] = __expf(Ps[i * pst + j] - m) * inv * drop_mult32(dc, base + j);
   }
   __syncthreads();
 
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void t5_attn_bwd_kernel(AttnP p) {
   float* lses = delta + TQ;
   const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const DropCtx dc = make_drop(p.seed, p.tag, p.p);
+  const DropCtx dc = drop_slab(make_drop(p.seed, p.tag, p.p), (uint32_t)(b * p.H + h));
 
   stage_kv<T>(reinterpret_cast<const T*>(p.k), p.ldk, b, h, Lk, dk, Ks, kst);
   stage_kv<T>(reinterpret_cast<const T*>(p.v), p.ldv, b, h, Lk, dk, Vs, kst);
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void t5_attn_bwd_kernel(AttnP p) {
         }
         if (p.bias) s += p.bias[((long)h * Lq + qi) * Lk + j];
         const float pr = __expf(s - lses[i]);
-        const float mlt = drop_mult(dc, (((uint64_t)b * p.H + h) * Lq + qi) * (uint64_t)Lk + j);
+        const float mlt = drop_mult32(dc, (uint32_t)qi * (uint32_t)Lk + j);
         pd = pr * mlt;
         ds = pr * (dpd * mlt - delta[i]);
         if (p.dbias) atomicAdd(p.dbias + ((long)h * Lq + qi) * Lk + j, ds);
@@ -250,6 +250,7 @@ static int set_lds(K kern, size_t bytes) { return ensure_dyn_lds(reinterpret_cas
 namespace klab {
 int t5_attn_fwd_mfma_dispatch(const klab_attn_args* a, hipStream_t s);  // attn_t5_mfma.hip
 int t5_attn_bwd_mfma_dispatch(const klab_attn_args* a, hipStream_t s);
+int dbias_reduce_dispatch(const void* ds_ws, float* dbias, int nbatch, int H, int Lq, int Lk, hipStream_t s);
 }
 using namespace klab;
 
@@ -306,6 +307,7 @@ extern "C" int klab_t5_attn_bwd(const klab_attn_args* a, void* stream) {
     rc = t5_attn_bwd_mfma_dispatch(a, (hipStream_t)stream);
     if (rc != KLAB_ERR_UNSUPPORTED) return rc;
   }
+  if (a->ds_defer) return KLAB_ERR_UNSUPPORTED;  // only the MFMA kernel stores dS; the caller retries without ds_defer
   const size_t es = a->dtype == KLAB_BF16 ? 2 : 4;
   const int vec = a->dtype == KLAB_BF16 ? 8 : 4;
   const size_t lds = 2 * (size_t)a->Lk * (a->dk + vec) * es + 2 * (size_t)a->Lk * a->dk * 4 + 2 * (size_t)TQ * a->dk * 4 +
@@ -322,4 +324,9 @@ extern "C" int klab_t5_attn_bwd(const klab_attn_args* a, void* stream) {
   }
   KLAB_LAUNCH_CHECK();
   return KLAB_OK;
+}
+
+extern "C" int klab_dbias_reduce(const void* ds_ws, int dtype, float* dbias, int nbatch, int H, int Lq, int Lk, void* stream) {
+  if (!ds_ws || !dbias || dtype != KLAB_BF16) return KLAB_ERR_BADARG;
+  return dbias_reduce_dispatch(ds_ws, dbias, nbatch, H, Lq, Lk, (hipStream_t)stream);
 }

@@ -35,6 +35,7 @@ struct AttnMP {
   bf16_t* dv; long lddv;
   float* dbias;
   bf16_t* ds_ws;
+  int defer_reduce;
 };
 
 template <int COLS> struct TrImg {  // rows = contraction index, columns = COLS 16-bit elements
@@ -152,13 +153,13 @@ __global__ __launch_bounds__(256) void t5_attn_fwd_mfma(AttnMP p) {
   sum += __shfl_xor(sum, 32, 64);
   const float inv = 1.f / sum;
   if (g == 0 && q < Lq && p.lse) p.lse[((long)b * p.H + h) * Lq + q] = m + __logf(sum);
-  const DropCtx dc = make_drop(p.seed, p.tag, p.p);
-  const uint64_t base = (((uint64_t)b * p.H + h) * Lq + qc) * (uint64_t)Lk;
+  const DropCtx dc = drop_slab(make_drop(p.seed, p.tag, p.p), (uint32_t)(b * p.H + h));
+  const uint32_t base = (uint32_t)qc * (uint32_t)Lk;
 #pragma unroll
   for (int t = 0; t < MAXT; ++t) {
     if (t < NT) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) s[t][r] *= inv * drop_mult(dc, base + t * 16 + g * 4 + r);
+      for (int r = 0; r < 4; ++r) s[t][r] *= inv * drop_mult32(dc, base + t * 16 + g * 4 + r);
     }
   }
   // O^T[d][q] = sum_key V[key][d] * P[q][key]
@@ -222,8 +223,7 @@ __global__ __launch_bounds__(256) void t5_attn_bwd_mfma(AttnMP p) {
     }
   }
   __syncthreads();
-  const DropCtx dc = make_drop(p.seed, p.tag, p.p);
-  const uint64_t bhbase = ((uint64_t)b * p.H + h) * (uint64_t)Lq;
+  const DropCtx dc = drop_slab(make_drop(p.seed, p.tag, p.p), (uint32_t)(b * p.H + h));
 
   // ---- phase A: swapped tiles, one query tile per wave iteration -> dQ ----
   for (int qt = wave; qt < NQ; qt += 4) {
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void t5_attn_bwd_mfma(AttnMP p) {
             float x = st[r];
             if (brow) x += brow[key];
             const float pr = __expf(x - lq);
-            dsv = pr * (dpt[r] * drop_mult(dc, (bhbase + q) * (uint64_t)Lk + key) - dq_);
+            dsv = pr * (dpt[r] * drop_mult32(dc, (uint32_t)q * (uint32_t)Lk + key) - dq_);
             if (dbrow) atomicAdd(dbrow + key, dsv);
           }
           ds2[u][r] = dsv;
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void t5_attn_bwd_mfma(AttnMP p) {
             float x = st[r];
             if (p.bias) x += p.bias[((long)h * Lq + q) * Lk + key];
             const float pr = __expf(x - lses[q]);
-            const float mlt = drop_mult(dc, (bhbase + q) * (uint64_t)Lk + key);
+            const float mlt = drop_mult32(dc, (uint32_t)q * (uint32_t)Lk + key);
             pdv = pr * mlt;
             dsv = pr * (dpt[r] * mlt - delta[q]);
           }
@@ -383,7 +383,7 @@ static int launch_bwd(const AttnMP& p, hipStream_t s) {
   if (rc) return rc;
   hipLaunchKernelGGL((t5_attn_bwd_mfma<DK>), dim3(p.B * p.H), dim3(256), lds, s, p);
   KLAB_LAUNCH_CHECK();
-  if (p.dbias && p.ds_ws) {
+  if (p.dbias && p.ds_ws && !p.defer_reduce) {
     const long tot = (long)p.H * p.Lq * p.Lk;
     hipLaunchKernelGGL(dbias_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, p.ds_ws, p.dbias, p.B, p.H * p.Lq, p.Lk, Lkp);
     KLAB_LAUNCH_CHECK();
@@ -398,6 +398,7 @@ static AttnMP to_mp(const klab_attn_args* a) {
   p.B = a->B; p.H = a->H; p.Lq = a->Lq; p.Lk = a->Lk; p.p = a->drop_p; p.seed = a->seed_dev; p.tag = a->drop_tag;
   p.dctx = (const bf16_t*)a->dctx; p.lddo = a->lddo; p.dq = (bf16_t*)a->dq; p.lddq = a->lddq; p.dkk = (bf16_t*)a->dk_out; p.lddk = a->lddk;
   p.dv = (bf16_t*)a->dv; p.lddv = a->lddv; p.dbias = a->dbias; p.ds_ws = (bf16_t*)a->ds_ws;
+  p.defer_reduce = a->ds_defer;
   return p;
 }
 
@@ -425,6 +426,15 @@ int t5_attn_bwd_mfma_dispatch(const klab_attn_args* a, hipStream_t s) {
     case 128: return launch_bwd<128>(p, s);
   }
   return KLAB_ERR_UNSUPPORTED;
+}
+
+
+int dbias_reduce_dispatch(const void* ds_ws, float* dbias, int nbatch, int H, int Lq, int Lk, hipStream_t s) {
+  const int Lkp = (Lk + 31) & ~31;
+  const long tot = (long)H * Lq * Lk;
+  hipLaunchKernelGGL(dbias_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, (const bf16_t*)ds_ws, dbias, nbatch, H * Lq, Lk, Lkp);
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
 }
 
 }  // namespace klab

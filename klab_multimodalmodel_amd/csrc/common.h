@@ -68,8 +68,19 @@ __device__ __forceinline__ DropCtx make_drop(const uint32_t* seed_dev, uint32_t 
 __device__ __forceinline__ float drop_mult(const DropCtx& d, uint64_t idx) {
   if (!d.on) return 1.f;
   uint32_t h = mix32((uint32_t)idx * 0x9E3779B1u + d.key);
-  h = mix32(h ^ ((uint32_t)(idx >> 32) * 0x85EBCA77u + 0x27D4EB2Fu));
+  const uint32_t hi = (uint32_t)(idx >> 32);
+  if (hi) h = mix32(h ^ (hi * 0x85EBCA77u + 0x27D4EB2Fu));  // second round only beyond 2^32 elements
   return h < d.thresh ? 0.f : d.scale;
+}
+// two-part index (slab, 32-bit offset inside the slab): the slab is folded into the key once per block, so an element
+// costs one hash round and no 64-bit index arithmetic (attention probabilities: slab = b*H + h, offset = q*Lk + key)
+__device__ __forceinline__ DropCtx drop_slab(DropCtx d, uint32_t slab) {
+  if (d.on) d.key = mix32(d.key ^ (slab * 0x85EBCA77u + 0x27D4EB2Fu));
+  return d;
+}
+__device__ __forceinline__ float drop_mult32(const DropCtx& d, uint32_t off) {
+  if (!d.on) return 1.f;
+  return mix32(off * 0x9E3779B1u + d.key) < d.thresh ? 0.f : d.scale;
 }
 
 // ---- wave / block reductions ---------------------------------------------------------------

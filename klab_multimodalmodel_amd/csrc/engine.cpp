@@ -416,7 +416,8 @@ size_t plan_workspace(klab_engine* e, void* base, int B, int Ls, int Lt) {
   e->dctx = b.take((size_t)Mx * inner * es);
   {
     const long Lmax = Le > Lt ? Le : Lt;
-    e->ds_ws = b.take((size_t)B * c.main.n_heads * Lmax * ((Lmax + 31) & ~31L) * es);
+    const int nlmax = c.main.n_layers > c.main.n_dec_layers ? c.main.n_layers : c.main.n_dec_layers;
+    e->ds_ws = b.take((size_t)nlmax * B * c.main.n_heads * Lmax * ((Lmax + 31) & ~31L) * es);  // one slab per layer
   }
 
   // ---- Swin ----
@@ -625,7 +626,7 @@ int t5_stack_backward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Pa
   float* dh_oth = e->dh_b;
   auto G = [&](int pi) { return Gflat + P[pi].grad_off; };
   const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
-  int dy_i = 0;
+  int dy_i = 0, deferred = 0;
   auto next_dy = [&]() { return e->dy_pool[dy_i++ % e->dy_pool.size()]; };
   RC(hipMemsetAsync(s.dbias, 0, (size_t)H * Lq * Lq * 4, c.s));
   // final norm: y = drop(norm(h[j])); previous sub-layer output dropout = FFN_OUT of the last layer
@@ -690,8 +691,16 @@ int t5_stack_backward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Pa
       a.drop_p = p; a.seed_dev = e->seed_dev; a.drop_tag = tag_of(stack_id, i, SITE_PROB);
       a.dctx = e->dctx; a.lddo = inner; a.dq = dqkv; a.lddq = 3 * inner;
       a.dk_out = eoff(c, dqkv, inner); a.lddk = 3 * inner; a.dv = eoff(c, dqkv, 2 * inner); a.lddv = 3 * inner;
-      a.dbias = s.dbias; a.ds_ws = e->ds_ws;
-      RC(klab_t5_attn_bwd(&a, c.ws()));
+      a.dbias = s.dbias;
+      int arc = KLAB_ERR_UNSUPPORTED;
+      if (c.dt == KLAB_BF16 && deferred == (int)L.size() - 1 - i) {  // store dS per layer; ONE reduction after the stack
+        a.ds_defer = 1;
+        a.ds_ws = (char*)e->ds_ws + (size_t)deferred * B * H * Lq * ((Lq + 31) & ~31) * c.es;
+        arc = klab_t5_attn_bwd(&a, c.ws());
+        if (arc == 0) ++deferred;
+      }
+      if (arc == KLAB_ERR_UNSUPPORTED) { a.ds_defer = 0; a.ds_ws = nullptr; arc = klab_t5_attn_bwd(&a, c.ws()); }
+      RC(arc);
     }
     RC(wgrad_side(c, dqkv, 3 * inner, b.xn1, d, M, 3 * inner, d, G(l.q)));  // q|k|v grads are adjacent
     RC(linear_dgrad(c, dqkv, 3 * inner, M, 3 * inner, P[l.q].warena_off, d, e->dxn, KLAB_F32));
@@ -703,6 +712,7 @@ int t5_stack_backward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Pa
       float* t = dh_cur; dh_cur = dh_oth; dh_oth = t;
     }
   }
+  if (deferred) RC(klab_dbias_reduce(e->ds_ws, c.dt, s.dbias, deferred * B, H, Lq, Lq, c.ws()));
   RC(klab_relbias_bwd(s.dbias, s.bucket, G(L[0].relb), H, Lq, Lq, cfg.rel_buckets, c.ws()));
   *dh_out = dh_cur;
   return 0;

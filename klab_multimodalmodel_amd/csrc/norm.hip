@@ -5,6 +5,7 @@
 // so that the Swin final LayerNorm and the language-encoder final RMS-norm write straight into the
 // [B, N_img + Ls, d] encoder-input buffer: the torch.cat of ref/models/model.py:23 costs nothing.
 #include "common.h"
+#include <stdlib.h>
 #include "klab_mm.h"
 
 namespace klab {
@@ -120,6 +121,77 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
       }
     }
   }
+}
+
+// Fused row + weight-gradient variant for d <= 256*SLOTS: the row's x / dy_eff stay in registers between the two passes,
+// each lane keeps the dw partial of its own columns over the block's rows, the 4 waves fold through LDS and a block
+// issues ONE f32 atomic per column (<= KLAB_RMS_BLOCKS-way contention; the un-reduced per-wave atomics were 10x slower).
+template <typename TY, int SLOTS>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             const float* __restrict__ w, const float* __restrict__ rstd,
+                                                             const float* __restrict__ dres, float* __restrict__ dx,
+                                                             TY* __restrict__ dxt, float* __restrict__ dw, int rows, int d,
+                                                             int grp, int grp_stride, int off, float p_y, uint32_t tag_y,
+                                                             float p_prev, uint32_t tag_prev, const uint32_t* seed) {
+  __shared__ float red[4][256 * SLOTS];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const DropCtx dcy = make_drop(seed, tag_y, p_y);
+  const DropCtx dcp = make_drop(seed, tag_prev, p_prev);
+  f32x4 g[SLOTS], acc[SLOTS];
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    const int c = lane * 4 + s * 256;
+    g[s] = c < d ? *reinterpret_cast<const f32x4*>(w + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (long row = (long)blockIdx.x * 4 + wv; row < rows; row += (long)gridDim.x * 4) {
+    const float* xr = x + row * d;
+    const long yrow = remap_row(row, grp, grp_stride, off);
+    const float* dyr = dy + yrow * d;
+    const float r = rstd[row];
+    f32x4 v[SLOTS], e[SLOTS];
+    float dot = 0.f;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      const int c = lane * 4 + s * 256;
+      if (c < d) {
+        v[s] = *reinterpret_cast<const f32x4*>(xr + c);
+        e[s] = *reinterpret_cast<const f32x4*>(dyr + c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          e[s][i] *= drop_mult(dcy, (uint64_t)yrow * d + c + i);
+          dot += e[s][i] * g[s][i] * v[s][i];
+          acc[s][i] += e[s][i] * v[s][i] * r;
+        }
+      }
+    }
+    dot = wave_sum(dot);
+    const float k = dot * r * r * r / (float)d;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      const int c = lane * 4 + s * 256;
+      if (c < d) {
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = r * g[s][i] * e[s][i] - v[s][i] * k;
+        if (dres) {
+          f32x4 q = *reinterpret_cast<const f32x4*>(dres + row * d + c);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[i] += q[i];
+        }
+        if (dx) store4<float>(dx + row * d + c, o[0], o[1], o[2], o[3]);
+        if (dxt) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[i] *= drop_mult(dcp, (uint64_t)row * d + c + i);
+          store4<TY>(dxt + row * d + c, o[0], o[1], o[2], o[3]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) *reinterpret_cast<f32x4*>(&red[wv][lane * 4 + s * 256]) = acc[s];
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += 256) atomicAdd(dw + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
 }
 
 // dw[c] += sum_rows dy_eff[row,c] * x[row,c] * rstd[row]: a column reduction, kept out of the row kernel
@@ -310,6 +382,18 @@ extern "C" int klab_rmsnorm_bwd(const float* dy, const float* x, const float* w,
   if (rows == 0) return KLAB_OK;
   hipStream_t s = (hipStream_t)stream;
   const int g = norm_grid(rows);
+  if (dw && d <= 1024) {  // fused row + dw kernel
+    static const int nblk = [] { const char* v = getenv("KLAB_RMS_BLOCKS"); int n = v ? atoi(v) : 512; return n < 1 ? 1 : n; }();
+    const int gf = g < nblk ? g : nblk;
+#define RB_LAUNCH(TY, SL)                                                                                                      \
+  hipLaunchKernelGGL((rmsnorm_bwd_dw_kernel<TY, SL>), dim3(gf), dim3(256), 0, s, dy, x, w, rstd, dres, dx, (TY*)dxt, dw, rows, d, grp, \
+                     grp_stride, off, p_y, tag_y, p_prev, tag_prev, seed_dev)
+    if (dxt_dtype == KLAB_BF16) { if (d <= 256) RB_LAUNCH(bf16_t, 1); else if (d <= 512) RB_LAUNCH(bf16_t, 2); else RB_LAUNCH(bf16_t, 4); }
+    else { if (d <= 256) RB_LAUNCH(float, 1); else if (d <= 512) RB_LAUNCH(float, 2); else RB_LAUNCH(float, 4); }
+#undef RB_LAUNCH
+    KLAB_LAUNCH_CHECK();
+    return KLAB_OK;
+  }
   if (dxt_dtype == KLAB_BF16)
     hipLaunchKernelGGL(rmsnorm_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, s, dy, x, w, rstd, dres, dx, (bf16_t*)dxt, rows,
                        d, grp, grp_stride, off, p_y, tag_y, p_prev, tag_prev, seed_dev);
