@@ -157,6 +157,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
+    host_ms = (time.perf_counter() - t0) / a.steps * 1e3  # host time to ENQUEUE a step (no device wait): < ms_per_step => GPU-bound
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
@@ -181,7 +182,7 @@ def main():
                        "global_batch": world * B, "per_gpu_batch": B, "src_len": Ls, "tgt_len": Lt,
                        "parallelism": f"dp{world}", "hipgraph": bool(core.use_graph), "fwd_bwd_gflop_per_sample": GFLOP_PER_SAMPLE["cfg2"],
                        "step_mfma_frac": round(B * GFLOP_PER_SAMPLE["cfg2"] / (ms * 1e-3) / 1e3 / PEAK_BF16_TFLOPS, 4),
-                       "final_loss": round(lossv, 4)},
+                       "host_enqueue_ms_per_step": round(host_ms, 3), "final_loss": round(lossv, 4)},
         }
         if launches > 0:
             avg_ms = probe_ms / launches

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libklab_mm.so")
 OBJDIR = os.path.join(HERE, "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
          "-Wno-unused-result"]
 
 

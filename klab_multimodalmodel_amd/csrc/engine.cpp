@@ -1158,9 +1158,10 @@ static int backward_segment(klab_engine* e, int segment, const float* dloss_dev,
       g.alpha = alpha; g.alpha_dev = dloss_dev; g.accumulate = 1; g.atomic_ok = 1;
       RC(klab_gemm(&g, cs.ws()));
     }
-    {  // d(dec_out) [Md,d] = dlogits [Md,V] @ shared [V,d]
+    {  // d(dec_out) [Md,d] = dlogits [Md,V] @ shared [V,d]: K = vocabulary over only Md*d outputs => split-K, f32 atomics
+      RC((int)hipMemsetAsync(e->dxn, 0, (size_t)Md * d * 4, c.s));
       klab_gemm_args g = G0(c, Md, d, V, e->logits, V, 1, woff(c, e->P[2][e->mi.shared].warena_off), d, 0, e->dxn, d, KLAB_F32);
-      g.alpha = alpha; g.alpha_dev = dloss_dev;
+      g.alpha = alpha; g.alpha_dev = dloss_dev; g.accumulate = 1; g.atomic_ok = 1;
       RC(klab_gemm(&g, c.ws()));
     }
     float* dh0 = nullptr;

@@ -17,6 +17,8 @@
 #include <mutex>
 
 #include "common.h"
+#include <type_traits>
+#include <utility>
 #include "klab_mm.h"
 
 #ifndef KLAB_GLDS_STAGES
@@ -350,13 +352,48 @@ template <int ROWS> __device__ __forceinline__ int mmajor_f(int kr) {
   else return ((kr >> 1) & 1) | (((kr >> 3) & 1) << 1);
 }
 
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+// The main loop below is scheduled by hand: LDS fragment reads, MFMAs and the counted waits are `asm volatile`, so
+// hipcc neither reorders them nor adds its own conservative s_waitcnt (a compiler-visible ds_read next to an asm one
+// made it drain lgkmcnt to 0 every k-tile; the ds_read_tr builtin made it drain vmcnt, i.e. the LDS-DMA ring).
+template <int OFF> __device__ __forceinline__ u32x4 lds_read_b128(unsigned addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+// 16x16x32 fragment half through the transposing read: 4 consecutive k of one m-column per lane (EXEC must be full)
+template <int OFF> __device__ __forceinline__ u32x2 lds_read_tr(unsigned addr) {
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+__device__ __forceinline__ void mfma_bf16_asm(f32x4& acc, const u32x4& x, const u32x4& y) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(x), "v"(y));
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+// at most g groups of LPS LDS-DMA instructions may stay in flight
+template <int LPS> __device__ __forceinline__ void wait_groups(int g) {
+  switch (g) {
+    case 0: wait_vmcnt<0>(); break;
+    case 1: wait_vmcnt<LPS>(); break;
+    case 2: wait_vmcnt<2 * LPS>(); break;
+    default: wait_vmcnt<3 * LPS>(); break;
+  }
+}
+
 template <int ROWS, bool KMAJOR>
 struct GldsOperand {
   static constexpr int L = ROWS / 64;              // LDS-DMA instructions per wave per stage
   static constexpr int BYTES = ROWS * 64;          // one stage of this operand
+  static constexpr int NF = ROWS / 32;             // 16-row fragments per wave (the wave owns ROWS/2 rows)
+  static constexpr int RPF = KMAJOR ? 1 : 2;       // LDS read instructions per fragment
   const bf16_t* src[L];
   long kstep;                                      // elements to advance per k-tile
-  __device__ __forceinline__ void init(const bf16_t* base, long ld, int row0, int nrows, int wave, int lane) {
+  unsigned foff[KMAJOR ? 1 : NF];                  // per-lane LDS byte offsets of the fragments inside a stage
+  __device__ __forceinline__ void init(const bf16_t* base, long ld, int row0, int nrows, int wave, int lane, int wrow0) {
     if constexpr (KMAJOR) {
       const int lrow = lane >> 2, lpos = lane & 3;
       const int lchunk = lpos ^ (((lrow >> 2) & 1) << 1);
@@ -367,6 +404,8 @@ struct GldsOperand {
         src[i] = base + (long)r * ld + lchunk * 8;
       }
       kstep = 32;
+      const int fr = lane & 15, fc = lane >> 4;    // fragment i sits 16 rows = 1024 B further: an immediate offset
+      foff[0] = (unsigned)((wrow0 + fr) * 64 + ((fc ^ (((fr >> 2) & 1) << 1)) * 16));
     } else {
       constexpr int CPR = ROWS / 8, KR = 64 / CPR;  // chunks per k-row, k-rows per wave-instruction
       const int kl = lane / CPR, pos = lane % CPR;
@@ -378,50 +417,53 @@ struct GldsOperand {
         src[i] = base + (long)kr * ld + m;
       }
       kstep = 32 * ld;
+      // two reads per fragment: k-rows kr0 = 8 g + q4 and kr0 + 4 (same swizzle term: f(kr0 + 4) == f(kr0)), so the
+      // second read is the first plus 4 k-rows = 8 * ROWS bytes, an immediate
+      const int g = lane >> 4, q4 = (lane & 15) >> 2, pp = lane & 3;
+      const int kr0 = 8 * g + q4;
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+        const int chunk = ((wrow0 + i * 16) >> 3) + (pp >> 1);
+        foff[i] = (unsigned)(kr0 * (ROWS * 2) + ((chunk ^ (mmajor_f<ROWS>(kr0) << 1)) * 16) + (pp & 1) * 8);
+      }
     }
   }
-  __device__ __forceinline__ void issue(int kt, char* stage, int wave) const {
-#pragma unroll
-    for (int i = 0; i < L; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + kt * kstep),
-                                       (__attribute__((address_space(3))) void*)(stage + (wave * L + i) * 1024), 16, 0, 0);
+  // LDS-DMA instruction i of k-tile kt into the stage at `stage`
+  __device__ __forceinline__ void issue1(int i, int kt, char* stage, int wave) const {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + kt * kstep),
+                                     (__attribute__((address_space(3))) void*)(stage + (wave * L + i) * 1024), 16, 0, 0);
   }
-  // fragment of 16 rows starting at r0 (32 k)
-  __device__ static __forceinline__ bf16x8 frag(const char* stage, int r0, int lane) {
+  // read instruction r (0 .. NF*RPF-1) of a stage whose byte address is sbase + SOFF; results land in fr[]
+  template <int R, int SOFF>
+  __device__ __forceinline__ void read1(unsigned sbase, u32x4 (&fr)[NF]) const {
     if constexpr (KMAJOR) {
-      const int fr = lane & 15, fc = lane >> 4;
-      return *reinterpret_cast<const bf16x8*>(stage + (r0 + fr) * 64 + ((fc ^ (((fr >> 2) & 1) << 1)) * 16));
+      fr[R] = lds_read_b128<SOFF + R * 1024>(sbase + foff[0]);
     } else {
-      // inline asm, not the builtin: hipcc puts s_waitcnt vmcnt(0) in front of the ds_read_tr builtin whenever an
-      // LDS-DMA is in flight (it cannot tell the ring slots apart), which drained the 3-deep prefetch every k-tile.
-      // The caller issues `s_waitcnt lgkmcnt(0)` + sched_barrier before the first MFMA (frag_wait()).
-      typedef __attribute__((address_space(3))) char lds_char;
-      typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-      const int g = lane >> 4, q4 = (lane & 15) >> 2, pp = lane & 3;
-      const int kr0 = 8 * g + q4, kr1 = kr0 + 4;
-      const int chunk = (r0 >> 3) + (pp >> 1);
-      const char* a0 = stage + kr0 * (ROWS * 2) + ((chunk ^ (mmajor_f<ROWS>(kr0) << 1)) * 16) + (pp & 1) * 8;
-      const char* a1 = stage + kr1 * (ROWS * 2) + ((chunk ^ (mmajor_f<ROWS>(kr1) << 1)) * 16) + (pp & 1) * 8;
-      const unsigned o0 = (unsigned)(uintptr_t)(lds_char*)a0, o1 = (unsigned)(uintptr_t)(lds_char*)a1;
-      u32x2 lo, hi;
-      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(o0) : "memory");
-      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(o1) : "memory");
-      typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-      const u32x4 both = {lo[0], lo[1], hi[0], hi[1]};
-      return __builtin_bit_cast(bf16x8, both);
+      constexpr int i = R >> 1;
+      const u32x2 h = lds_read_tr<SOFF + (R & 1) * 8 * ROWS>(sbase + foff[i]);
+      if constexpr ((R & 1) == 0) { fr[i][0] = h[0]; fr[i][1] = h[1]; }
+      else { fr[i][2] = h[0]; fr[i][3] = h[1]; }
     }
   }
 };
 
+// Software-pipelined, hand-scheduled main loop.  Per k-tile t a wave: waits until k-tile t+1 has landed (counted
+// vmcnt) + one s_barrier, then issues its MFMAs on the fragments of t (already in registers) with the LDS reads of
+// t+1 (other register set) and the LDS-DMA of t+S-1 slotted into the gaps between them.  Before this rewrite the
+// three phases ran back to back in each wave (measured additive: DMA issue + LDS latency + MFMA).
 template <int BM, int BN, bool AK, bool BKM, bool ATOMIC>
 __device__ __forceinline__ void gemm_glds_body(const GemmP& p) {
   typedef bf16_t T;
   constexpr int BK = 32, S = KLAB_GLDS_STAGES;
+  static_assert(S == 4, "the steady-state loop is unrolled over a 4-stage ring");
   constexpr int WTM = BM / 2, WTN = BN / 2, MI = WTM / 16, NI = WTN / 16;
   typedef GldsOperand<BM, AK> OA;
   typedef GldsOperand<BN, BKM> OB;
   constexpr int ABYTES = OA::BYTES, STAGE = OA::BYTES + OB::BYTES;
-  constexpr int LPS = OA::L + OB::L;  // LDS-DMA instructions per wave per stage
+  constexpr int LPS = OA::L + OB::L;                    // LDS-DMA instructions per wave per stage
+  constexpr int NRA = MI * OA::RPF, NRB = NI * OB::RPF;  // LDS read instructions per wave per k-tile
+  constexpr int NMMA = MI * NI, NOTH = NRA + NRB + LPS;
+  static_assert(S * STAGE <= 65536, "immediate LDS offsets");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -437,71 +479,136 @@ __device__ __forceinline__ void gemm_glds_body(const GemmP& p) {
   if (nt <= 0) return;
 
   OA oa; OB ob;
-  oa.init(reinterpret_cast<const T*>(p.A), p.lda, bm0, p.M, wave, lane);
-  ob.init(reinterpret_cast<const T*>(p.B), p.ldb, bn0, p.N, wave, lane);
+  oa.init(reinterpret_cast<const T*>(p.A), p.lda, bm0, p.M, wave, lane, wm);
+  ob.init(reinterpret_cast<const T*>(p.B), p.ldb, bn0, p.N, wave, lane, wn);
   // k-tiles are visited in a per-workgroup rotated order: workgroups that share an A or B panel start together,
   // and in lockstep they would all hit the same few L2 channels at once; rotating by the tile coordinates spreads
   // each panel's readers over its whole K extent (only the fp32 summation order changes).
   const int skew = ((bm0 / BM) * 5 + (bn0 / BN) * 3) % nt;
-  auto issue = [&](int t, int stage) {
-    char* sa = smem + stage * STAGE;
-    int kk = t + skew;
-    kk = kk >= nt ? kk - nt : kk;
-    oa.issue(kt0 + kk, sa, wave);
-    ob.issue(kt0 + kk, sa + ABYTES, wave);
-  };
+  auto ktile = [&](int t) { int kk = t + skew; return kt0 + (kk >= nt ? kk - nt : kk); };
+  const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
   f32x4 acc[MI][NI];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 a0[MI], b0[NI], a1[MI], b1[NI];
 
-  const bool do_load = !(p.ablate & 1), do_mma = !(p.ablate & 2), do_frag = !(p.ablate & 4);
-#pragma unroll
-  for (int t = 0; t < S - 1; ++t)
-    if (t < nt && do_load) issue(t, t);
-
-  bf16x8 af[MI], bfr[NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i) af[i] = bf16x8{};
-#pragma unroll
-  for (int j = 0; j < NI; ++j) bfr[j] = bf16x8{};
-  for (int t = 0; t < nt; ++t) {
-    const int ahead = nt - 1 - t;  // k-tiles issued after tile t that may stay in flight
-    if (ahead >= S - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * LPS) : "memory");
-    else if (S > 3 && ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
-    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // tile t visible to every wave; every wave is done reading tile t-1's stage
-    if (t + S - 1 < nt && do_load) issue(t + S - 1, (t + S - 1) % S);
-    const char* ta = smem + (t % S) * STAGE;
-    const char* tb = ta + ABYTES;
-    if (do_frag) {
-#pragma unroll
-      for (int i = 0; i < MI; ++i) af[i] = OA::frag(ta, wm + i * 16, lane);
-#pragma unroll
-      for (int j = 0; j < NI; ++j) bfr[j] = OB::frag(tb, wn + j * 16, lane);
-      if constexpr (!AK || !BKM) {  // asm transposed reads are invisible to the compiler's lgkmcnt bookkeeping
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    if (do_mma) {
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-          if constexpr (ATOMIC) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-        }
-    } else {
-#pragma unroll
-      for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(af[i]));
-#pragma unroll
-      for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(bfr[j]));
-    }
+  // "other" operation o of a step: first the LDS reads of the next k-tile (early, so they have the rest of the step to
+  // land), then the LDS-DMA instructions.  SN = ring slot of the k-tile being read, SD = slot being refilled.
+#define KLAB_OTHER(O, SN, SD, NA, NB, DO_DMA, KT)                                                          \
+  if constexpr ((O) < NRA) oa.template read1<(O), (SN) * STAGE>(sbase, NA);                                \
+  else if constexpr ((O) < NRA + NRB) ob.template read1<(O) - NRA, (SN) * STAGE + ABYTES>(sbase, NB);       \
+  else if (DO_DMA) {                                                                                       \
+    constexpr int d = (O) - NRA - NRB;                                                                     \
+    if constexpr (d < OA::L) oa.issue1(d, KT, smem + (SD) * STAGE, wave);                                  \
+    else ob.issue1(d - OA::L, KT, smem + (SD) * STAGE + ABYTES, wave);                                     \
   }
+  // MFMAs of the current fragments (CA, CB) with the other operations spread between them
+  auto mma_and = [&](auto sn_c, auto sd_c, const u32x4 (&ca)[MI], const u32x4 (&cb)[NI], u32x4 (&na)[MI], u32x4 (&nb)[NI],
+                     bool do_read, bool do_dma, int kt) {
+    constexpr int SN = decltype(sn_c)::value, SD = decltype(sd_c)::value;
+    auto other = [&](auto oc) {
+      constexpr int O = decltype(oc)::value;
+      if constexpr (O < NRA + NRB) { if (do_read) { KLAB_OTHER(O, SN, SD, na, nb, false, kt) } }
+      else { KLAB_OTHER(O, SN, SD, na, nb, do_dma, kt) }
+    };
+    auto unroll_other = [&](auto kc) {  // operations [k*NOTH/NMMA, (k+1)*NOTH/NMMA)
+      constexpr int k = decltype(kc)::value, lo = k * NOTH / NMMA, hi = (k + 1) * NOTH / NMMA;
+      if constexpr (hi - lo > 0) other(std::integral_constant<int, lo>{});
+      if constexpr (hi - lo > 1) other(std::integral_constant<int, lo + 1>{});
+      if constexpr (hi - lo > 2) other(std::integral_constant<int, lo + 2>{});
+      if constexpr (hi - lo > 3) other(std::integral_constant<int, lo + 3>{});
+      static_assert(hi - lo <= 4, "at most four slotted operations per MFMA gap");
+    };
+    auto one = [&](auto kc) {
+      constexpr int k = decltype(kc)::value, i = k / NI, j = k % NI;
+      if constexpr (ATOMIC) mfma_bf16_asm(acc[i][j], ca[i], cb[j]);
+      else mfma_bf16_asm(acc[i][j], cb[j], ca[i]);
+      unroll_other(kc);
+    };
+    [&]<int... Ks>(std::integer_sequence<int, Ks...>) { (one(std::integral_constant<int, Ks>{}), ...); }(std::make_integer_sequence<int, NMMA>{});
+  };
+
+  // prologue: k-tiles 0 .. S-1 fill the whole ring, the fragments of k-tile 0 come in
+#pragma unroll
+  for (int t = 0; t < S; ++t)
+    if (t < nt) {
+#pragma unroll
+      for (int d = 0; d < OA::L; ++d) oa.issue1(d, ktile(t), smem + t * STAGE, wave);
+#pragma unroll
+      for (int d = 0; d < OB::L; ++d) ob.issue1(d, ktile(t), smem + t * STAGE + ABYTES, wave);
+    }
+  wait_groups<LPS>((nt < S ? nt : S) - 1);  // k-tile 0 has landed
+  __builtin_amdgcn_s_barrier();
+  [&]<int... Rs>(std::integer_sequence<int, Rs...>) { (oa.template read1<Rs, 0>(sbase, a0), ...); }(std::make_integer_sequence<int, NRA>{});
+  [&]<int... Rs>(std::integer_sequence<int, Rs...>) { (ob.template read1<Rs, ABYTES>(sbase, b0), ...); }(std::make_integer_sequence<int, NRB>{});
+
+  int t = 0;
+  // one pipeline step on k-tile t held in (CA, CB) = ring slot SC: once every wave has its fragments of t in registers
+  // (lgkmcnt + barrier) slot SC is refilled with k-tile t+S, while k-tile t+1 (slot SC+1) is read into (NA, NB)
+#define KLAB_STEP(SC, CA, CB, NA, NB)                                                                                  \
+  {                                                                                                                   \
+    wait_lgkmcnt<0>();              /* fragments of k-tile t (issued one step ago) */                                  \
+    wait_vmcnt<(S - 2) * LPS>();    /* k-tile t+1 landed; S-2 younger groups stay in flight */                         \
+    __builtin_amdgcn_s_barrier();   /* t+1 visible to all waves; all waves hold k-tile t in registers: slot SC is free */ \
+    mma_and(std::integral_constant<int, ((SC) + 1) % S>{}, std::integral_constant<int, (SC)>{}, CA, CB, NA, NB, true, true, ktile(t + S)); \
+    ++t;                                                                                                              \
+  }
+  while (t + S + 3 < nt) {  // four straight-line steps: every step still has a k-tile to issue
+    KLAB_STEP(0, a0, b0, a1, b1)
+    KLAB_STEP(1, a1, b1, a0, b0)
+    KLAB_STEP(2, a0, b0, a1, b1)
+    KLAB_STEP(3, a1, b1, a0, b0)
+  }
+#undef KLAB_STEP
+  // Tail (t is a multiple of S; at most S+3 k-tiles): not pipelined.  Each step reads its own fragments into (a1, b1)
+  // and consumes them at once, so no asm-loaded register is live across a branch: hipcc copies such values at control
+  // flow merges, and a copy placed right behind the asm ds_read would pick the register up before the data lands.
+  auto mma_plain = [&](const u32x4 (&ca)[MI], const u32x4 (&cb)[NI]) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        if constexpr (ATOMIC) mfma_bf16_asm(acc[i][j], ca[i], cb[j]);
+        else mfma_bf16_asm(acc[i][j], cb[j], ca[i]);
+      }
+  };
+#define KLAB_TAIL(SC, FIRST)                                                                                              \
+  {                                                                                                                     \
+    if constexpr (!(FIRST)) {                                                                                           \
+      const int rem = nt - 1 - t;                                                                                       \
+      wait_groups<LPS>(rem < S - 1 ? rem : S - 1); /* k-tile t landed */                                                 \
+      __builtin_amdgcn_s_barrier();               /* ... for every wave */                                              \
+      [&]<int... Rs>(std::integer_sequence<int, Rs...>) { (oa.template read1<Rs, (SC) * STAGE>(sbase, a1), ...); }(std::make_integer_sequence<int, NRA>{});          \
+      [&]<int... Rs>(std::integer_sequence<int, Rs...>) { (ob.template read1<Rs, (SC) * STAGE + ABYTES>(sbase, b1), ...); }(std::make_integer_sequence<int, NRB>{}); \
+    }                                                                                                                   \
+    wait_lgkmcnt<0>();                                                                                                  \
+    if (t + S < nt) {                                                                                                   \
+      __builtin_amdgcn_s_barrier(); /* every wave holds k-tile t in registers: slot SC is free */                        \
+      _Pragma("unroll") for (int d = 0; d < OA::L; ++d) oa.issue1(d, ktile(t + S), smem + (SC) * STAGE, wave);           \
+      _Pragma("unroll") for (int d = 0; d < OB::L; ++d) ob.issue1(d, ktile(t + S), smem + (SC) * STAGE + ABYTES, wave);  \
+    }                                                                                                                   \
+    if constexpr (FIRST) mma_plain(a0, b0); /* prefetched by the prologue or by the last steady step */                  \
+    else mma_plain(a1, b1);                                                                                             \
+    ++t;                                                                                                                \
+  }
+  KLAB_TAIL(0, true)
+  while (t < nt) {
+    KLAB_TAIL(1, false)
+    if (t >= nt) break;
+    KLAB_TAIL(2, false)
+    if (t >= nt) break;
+    KLAB_TAIL(3, false)
+    if (t >= nt) break;
+    KLAB_TAIL(0, false)
+  }
+#undef KLAB_TAIL
+#undef KLAB_OTHER
+  // MFMA results are not interlocked against the v_accvgpr_read of the epilogue when the MFMA is inline asm
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  wait_vmcnt<0>();
   float alpha = p.alpha;
   if (p.alpha_dev) alpha *= p.alpha_dev[0];
   if constexpr (ATOMIC) {
@@ -711,6 +818,15 @@ static int dispatch_tile(GemmP& p, bool atomic_ok, hipStream_t s) {
   const int BK = MmaTraits<T>::BK;
   const int nt = (p.K + BK - 1) / BK;
   p.splits = 1;
+  if (atomic_ok && nt >= 256 && p.M >= 128 && p.N >= 64 && tiles(128, 64) < 1024) {
+    // very long K over few tiles (LM-head dgrad: K = vocabulary): one workgroup per CU streams its operands from HBM
+    // with too little in flight; split K so that ~4 workgroups share a CU
+    const long t = tiles(128, 64);
+    long sp = (1024 + t - 1) / t;
+    if (sp > nt / 64) sp = nt / 64;
+    if (sp > 16) sp = 16;
+    if (sp >= 2) { p.splits = (int)sp; return dispatch_layout<T, 128, 64>(p, true, s); }
+  }
   if (tiles(128, 128) >= 240) return dispatch_layout<T, 128, 128>(p, false, s);
   if (tiles(128, 64) >= 240) return dispatch_layout<T, 128, 64>(p, false, s);
   if (atomic_ok && nt >= 16) {

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Static check of the hand-scheduled GEMM loops in a hipcc -S dump: between a kernel's first s_barrier and the
+`s_nop 15` that closes the main loop, no instruction other than v_mfma may READ a register that an inline-asm
+ds_read wrote (hipcc does not know that data lands late; a copy there would pick up stale data).
+usage: check_gemm_asm.py gemm.s"""
+import re, sys
+
+def regs(tok):
+    m = re.match(r"v\[(\d+):(\d+)\]", tok)
+    if m: return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"v(\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+
+def main(path):
+    name, body, bad, nk = None, [], 0, 0
+    def check(name, body):
+        nonlocal bad, nk
+        try:
+            i0 = next(i for i, l in enumerate(body) if "s_barrier" in l)
+            i1 = next(i for i, l in enumerate(body) if "s_nop 15" in l)
+        except StopIteration:
+            return
+        nk += 1
+        pending = set()   # registers written by ds_read since the last lgkmcnt wait
+        for l in body[i0:i1]:
+            t = l.strip()
+            if not t or t.startswith(";") or t.startswith("."): continue
+            op, _, rest = t.partition(" ")
+            ops = [o.strip() for o in rest.split(",")]
+            if op.startswith("ds_read"):
+                pending |= regs(ops[0]); continue
+            if op == "s_waitcnt" and "lgkmcnt(0)" in t:
+                pending = set(); continue
+            if op.startswith("v_mfma") or op.startswith("s_") or not ops: continue
+            srcs = set()
+            for o in ops[1:]: srcs |= regs(o.split(" ")[0])
+            if op.startswith("global_load_lds"): srcs |= regs(ops[0])
+            if srcs & pending:
+                bad += 1
+                print(f"{name}: `{t}` reads {sorted(srcs & pending)} before the LDS data has landed")
+    for line in open(path):
+        m = re.match(r"^(_ZN4klab\w*(gemm_glds_kernel|klab_lmhead_gemm)\w*):", line)
+        if m:
+            if name: check(name, body)
+            name, body = m.group(1), []
+        elif name:
+            body.append(line)
+            if "s_endpgm" in line:
+                check(name, body); name = None
+    print(f"checked {nk} kernels, {bad} premature reads")
+    return 1 if bad else 0
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1]))

@@ -10,7 +10,7 @@ from klab_multimodalmodel_amd import ops  # noqa: E402
 
 SHAPES = [  # name, M, N, K, a_kmajor, b_kmajor, atomic
     ("lmhead fwd", 4096, 32128, 512, True, True, False),
-    ("lmhead dgrad", 4096, 512, 32128, True, False, False),
+    ("lmhead dgrad", 4096, 512, 32128, True, False, True),
     ("lmhead wgrad", 32128, 512, 4096, False, False, True),
     ("qkv fwd", 4096, 1536, 512, True, True, False),
     ("o fwd", 4096, 512, 512, True, True, False),
@@ -37,7 +37,10 @@ SHAPES = [  # name, M, N, K, a_kmajor, b_kmajor, atomic
 def main():
     dt = torch.bfloat16
     tot = 0.0
+    flt = sys.argv[1:]
     for name, M, N, K, ak, bk, atomic in SHAPES:
+        if flt and not any(f in name for f in flt):
+            continue
         A = torch.randn((M, K) if ak else (K, M), device="cuda").to(dt)
         B = torch.randn((N, K) if bk else (K, N), device="cuda").to(dt)
         C = torch.zeros(M, N, device="cuda", dtype=torch.float32 if atomic else dt)
