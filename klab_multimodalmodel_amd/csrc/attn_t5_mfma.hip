@@ -211,13 +211,24 @@ __global__ __launch_bounds__(256) void t5_attn_bwd_mfma(AttnMP p) {
   stage<DK, DKP, true, true>(p.k, p.ldk, b, h, Lk, Lkp, Kr, KPITCH, Kt);
   stage<DK, DKP, true, false>(p.v, p.ldv, b, h, Lk, Lkp, Vr, KPITCH, nullptr);
   stage<DK, DKP, true, true>(p.dctx, p.lddo, b, h, Lq, Lqp, dOr, KPITCH, dOt);
-  for (int qq = wave; qq < Lqp; qq += 4) {
+  // delta[q] = dO[q,:] . O[q,:] and the row's log-sum-exp: 4 lanes per row with 8-byte loads, all rows of the block in
+  // flight at once (one row per wave at a time made this ~20 dependent global round trips, most of the kernel's time)
+  for (int r0 = 0; r0 < Lqp; r0 += 64) {
+    constexpr int EPS = DK / 4;
+    const int qq = r0 + (threadIdx.x >> 2), seg = threadIdx.x & 3;
     float a = 0.f;
-    if (qq < Lq)
-      for (int c = lane; c < DK; c += 64)
-        a += (float)p.dctx[((long)b * Lq + qq) * p.lddo + (long)h * DK + c] * (float)p.ctx[((long)b * Lq + qq) * p.ldo + (long)h * DK + c];
-    a = wave_sum(a);
-    if (lane == 0) {
+    if (qq < Lq) {
+      const bf16_t* dop = p.dctx + ((long)b * Lq + qq) * p.lddo + (long)h * DK + seg * EPS;
+      const bf16_t* op = p.ctx + ((long)b * Lq + qq) * p.ldo + (long)h * DK + seg * EPS;
+#pragma unroll
+      for (int c = 0; c < EPS; c += 4) {
+        const bf16x4 x = *reinterpret_cast<const bf16x4*>(dop + c), y = *reinterpret_cast<const bf16x4*>(op + c);
+        a += (float)x[0] * (float)y[0] + (float)x[1] * (float)y[1] + (float)x[2] * (float)y[2] + (float)x[3] * (float)y[3];
+      }
+    }
+    a += __shfl_xor(a, 1, 64);
+    a += __shfl_xor(a, 2, 64);
+    if (seg == 0 && qq < Lqp) {
       delta[qq] = a;
       lses[qq] = qq < Lq ? p.lse[((long)b * p.H + h) * Lq + qq] : INFINITY;  // padded queries: P = exp(-inf) = 0
     }
@@ -339,16 +350,20 @@ __global__ __launch_bounds__(256) void t5_attn_bwd_mfma(AttnMP p) {
   }
 }
 
-// dbias[h,q,k] += sum_b dS[b,h,q,k]  (fixed order: bit-reproducible)
+// dbias[h,q,k] += sum_b dS[b,h,q,k].  gridDim.y == 1: fixed order, bit-reproducible; gridDim.y > 1 (many slabs, e.g. all
+// layers of a stack at once): each y reduces a contiguous chunk of slabs and adds its partial with one f32 atomic.
 __global__ __launch_bounds__(256) void dbias_reduce_kernel(const bf16_t* __restrict__ ds, float* __restrict__ dbias, int B, int HLq, int Lk, int Lkp) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)HLq * Lk) return;
   const long row = idx / Lk;
   const int k = idx % Lk;
+  const int per = (B + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = b0 + per < B ? b0 + per : B;
   float a = 0.f;
 #pragma unroll 16
-  for (int b = 0; b < B; ++b) a += (float)ds[((long)b * HLq + row) * Lkp + k];  // independent loads: keep many in flight
-  dbias[idx] += a;
+  for (int b = b0; b < b1; ++b) a += (float)ds[((long)b * HLq + row) * Lkp + k];  // independent loads: keep many in flight
+  if (gridDim.y == 1) dbias[idx] += a;
+  else if (b1 > b0) atomicAdd(dbias + idx, a);
 }
 
 template <typename K>
@@ -432,7 +447,10 @@ int t5_attn_bwd_mfma_dispatch(const klab_attn_args* a, hipStream_t s) {
 int dbias_reduce_dispatch(const void* ds_ws, float* dbias, int nbatch, int H, int Lq, int Lk, hipStream_t s) {
   const int Lkp = (Lk + 31) & ~31;
   const long tot = (long)H * Lq * Lk;
-  hipLaunchKernelGGL(dbias_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, (const bf16_t*)ds_ws, dbias, nbatch, H * Lq, Lk, Lkp);
+  int gy = nbatch / 16;  // >= 16 slabs per chunk
+  gy = gy < 1 ? 1 : (gy > 32 ? 32 : gy);
+  if (nbatch <= 64) gy = 1;
+  hipLaunchKernelGGL(dbias_reduce_kernel, dim3((unsigned)((tot + 255) / 256), gy), dim3(256), 0, s, (const bf16_t*)ds_ws, dbias, nbatch, H * Lq, Lk, Lkp);
   KLAB_LAUNCH_CHECK();
   return KLAB_OK;
 }

@@ -1152,17 +1152,19 @@ static int backward_segment(klab_engine* e, int segment, const float* dloss_dev,
     const int Md = B * e->Lt, V = cfg.main.vocab;
     const float alpha = cfg.main.scale_decoder_outputs ? 1.f / sqrtf((float)d) : 1.f;
     Ctx cs{e, e->side, c.dt, c.es};
-    RC(side_after_main(c));
-    {  // d shared [V,d] = dlogits^T @ dec_out  (first of the tied weight's three contributors) -- side stream
-      klab_gemm_args g = G0(cs, V, d, Md, e->logits, V, 0, e->dec.out_t, d, 0, Gm + e->P[2][e->mi.shared].grad_off, d, KLAB_F32);
-      g.alpha = alpha; g.alpha_dev = dloss_dev; g.accumulate = 1; g.atomic_ok = 1;
-      RC(klab_gemm(&g, cs.ws()));
-    }
     {  // d(dec_out) [Md,d] = dlogits [Md,V] @ shared [V,d]: K = vocabulary over only Md*d outputs => split-K, f32 atomics
       RC((int)hipMemsetAsync(e->dxn, 0, (size_t)Md * d * 4, c.s));
       klab_gemm_args g = G0(c, Md, d, V, e->logits, V, 1, woff(c, e->P[2][e->mi.shared].warena_off), d, 0, e->dxn, d, KLAB_F32);
       g.alpha = alpha; g.alpha_dev = dloss_dev; g.accumulate = 1; g.atomic_ok = 1;
       RC(klab_gemm(&g, c.ws()));
+    }
+    // the weight gradient trails BEHIND the dgrad on the side stream (run side by side the two chip-filling GEMMs took
+    // longer than one after the other); it then overlaps the decoder's first, latency-bound backward kernels
+    RC(side_after_main(c));
+    {  // d shared [V,d] = dlogits^T @ dec_out  (first of the tied weight's three contributors)
+      klab_gemm_args g = G0(cs, V, d, Md, e->logits, V, 0, e->dec.out_t, d, 0, Gm + e->P[2][e->mi.shared].grad_off, d, KLAB_F32);
+      g.alpha = alpha; g.alpha_dev = dloss_dev; g.accumulate = 1; g.atomic_ok = 1;
+      RC(klab_gemm(&g, cs.ws()));
     }
     float* dh0 = nullptr;
     RC(t5_stack_backward(c, cfg.main, e->P[2], e->W[2], Gm, e->mi.dec, e->mi.dec_final, e->dec, true, STACK_DEC, p, B, e->kv_all, e->dkv_all,

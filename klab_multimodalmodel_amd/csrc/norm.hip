@@ -127,13 +127,15 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
 // each lane keeps the dw partial of its own columns over the block's rows, the 4 waves fold through LDS and a block
 // issues ONE f32 atomic per column (<= KLAB_RMS_BLOCKS-way contention; the un-reduced per-wave atomics were 10x slower).
 template <typename TY, int SLOTS>
-__global__ __launch_bounds__(256) void rmsnorm_bwd_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+__global__ __launch_bounds__(1024) void rmsnorm_bwd_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              const float* __restrict__ w, const float* __restrict__ rstd,
                                                              const float* __restrict__ dres, float* __restrict__ dx,
                                                              TY* __restrict__ dxt, float* __restrict__ dw, int rows, int d,
                                                              int grp, int grp_stride, int off, float p_y, uint32_t tag_y,
                                                              float p_prev, uint32_t tag_prev, const uint32_t* seed) {
-  __shared__ float red[4][256 * SLOTS];
+  constexpr int WPB = 16;  // 16 waves per workgroup: one row per wave in flight (the kernel is latency-bound), and the
+                           // weight-gradient partials of 16+ rows fold into ONE atomic per column
+  __shared__ float red[WPB][256 * SLOTS];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const DropCtx dcy = make_drop(seed, tag_y, p_y);
   const DropCtx dcp = make_drop(seed, tag_prev, p_prev);
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_dw_kernel(const float* __rest
     g[s] = c < d ? *reinterpret_cast<const f32x4*>(w + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  for (long row = (long)blockIdx.x * 4 + wv; row < rows; row += (long)gridDim.x * 4) {
+  for (long row = (long)blockIdx.x * WPB + wv; row < rows; row += (long)gridDim.x * WPB) {
     const float* xr = x + row * d;
     const long yrow = remap_row(row, grp, grp_stride, off);
     const float* dyr = dy + yrow * d;
@@ -191,7 +193,12 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_dw_kernel(const float* __rest
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) *reinterpret_cast<f32x4*>(&red[wv][lane * 4 + s * 256]) = acc[s];
   __syncthreads();
-  for (int c = threadIdx.x; c < d; c += 256) atomicAdd(dw + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+  for (int c = threadIdx.x; c < d; c += 1024) {
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < WPB; ++w) a += red[w][c];
+    atomicAdd(dw + c, a);
+  }
 }
 
 // dw[c] += sum_rows dy_eff[row,c] * x[row,c] * rstd[row]: a column reduction, kept out of the row kernel
@@ -384,9 +391,10 @@ extern "C" int klab_rmsnorm_bwd(const float* dy, const float* x, const float* w,
   const int g = norm_grid(rows);
   if (dw && d <= 1024) {  // fused row + dw kernel
     static const int nblk = [] { const char* v = getenv("KLAB_RMS_BLOCKS"); int n = v ? atoi(v) : 512; return n < 1 ? 1 : n; }();
-    const int gf = g < nblk ? g : nblk;
+    const int g16 = (rows + 15) / 16;
+    const int gf = g16 < nblk ? g16 : nblk;
 #define RB_LAUNCH(TY, SL)                                                                                                      \
-  hipLaunchKernelGGL((rmsnorm_bwd_dw_kernel<TY, SL>), dim3(gf), dim3(256), 0, s, dy, x, w, rstd, dres, dx, (TY*)dxt, dw, rows, d, grp, \
+  hipLaunchKernelGGL((rmsnorm_bwd_dw_kernel<TY, SL>), dim3(gf), dim3(1024), 0, s, dy, x, w, rstd, dres, dx, (TY*)dxt, dw, rows, d, grp, \
                      grp_stride, off, p_y, tag_y, p_prev, tag_prev, seed_dev)
     if (dxt_dtype == KLAB_BF16) { if (d <= 256) RB_LAUNCH(bf16_t, 1); else if (d <= 512) RB_LAUNCH(bf16_t, 2); else RB_LAUNCH(bf16_t, 4); }
     else { if (d <= 256) RB_LAUNCH(float, 1); else if (d <= 512) RB_LAUNCH(float, 2); else RB_LAUNCH(float, 4); }
