@@ -207,10 +207,51 @@ __global__ __launch_bounds__(256) void t5_attn_bwd_mfma(AttnMP p) {
   const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
 
-  stage<DK, DKP, true, true>(p.q, p.ldq, b, h, Lq, Lqp, Qr, KPITCH, Qt);
-  stage<DK, DKP, true, true>(p.k, p.ldk, b, h, Lk, Lkp, Kr, KPITCH, Kt);
-  stage<DK, DKP, true, false>(p.v, p.ldv, b, h, Lk, Lkp, Vr, KPITCH, nullptr);
-  stage<DK, DKP, true, true>(p.dctx, p.lddo, b, h, Lq, Lqp, dOr, KPITCH, dOt);
+  {
+    // all global loads of the four operand slices go out before the first LDS store (one memory round trip instead of
+    // one per chunk: the per-matrix loops were 8-12 dependent load -> store pairs)
+    constexpr int CPR = DKP / 8, MAXC = 4;
+    const int nq = Lqp * CPR, nk = Lkp * CPR;
+    if (nq <= MAXC * 256 && nk <= MAXC * 256) {
+      bf16x8 vq[MAXC], vk[MAXC], vv[MAXC], vd[MAXC];
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i) {
+        const int ch = threadIdx.x + i * 256, r = ch / CPR, c = (ch % CPR) * 8;
+        vq[i] = bf16x8{}; vk[i] = bf16x8{}; vv[i] = bf16x8{}; vd[i] = bf16x8{};
+        if (ch < nq && r < Lq && c < DK) {
+          vq[i] = *reinterpret_cast<const bf16x8*>(p.q + ((long)b * Lq + r) * p.ldq + (long)h * DK + c);
+          vd[i] = *reinterpret_cast<const bf16x8*>(p.dctx + ((long)b * Lq + r) * p.lddo + (long)h * DK + c);
+        }
+        if (ch < nk && r < Lk && c < DK) {
+          vk[i] = *reinterpret_cast<const bf16x8*>(p.k + ((long)b * Lk + r) * p.ldk + (long)h * DK + c);
+          vv[i] = *reinterpret_cast<const bf16x8*>(p.v + ((long)b * Lk + r) * p.ldv + (long)h * DK + c);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i) {
+        const int ch = threadIdx.x + i * 256, r = ch / CPR, c = (ch % CPR) * 8;
+        const bool tr = c < ((DK + 15) / 16) * 16;
+        if (ch < nq) {
+          *reinterpret_cast<bf16x8*>(Qr + r * KPITCH + c * 2) = vq[i];
+          *reinterpret_cast<bf16x8*>(dOr + r * KPITCH + c * 2) = vd[i];
+          if (tr) {
+            *reinterpret_cast<bf16x8*>(Qt + TrImg<DKP>::off(r, c)) = vq[i];
+            *reinterpret_cast<bf16x8*>(dOt + TrImg<DKP>::off(r, c)) = vd[i];
+          }
+        }
+        if (ch < nk) {
+          *reinterpret_cast<bf16x8*>(Kr + r * KPITCH + c * 2) = vk[i];
+          *reinterpret_cast<bf16x8*>(Vr + r * KPITCH + c * 2) = vv[i];
+          if (tr) *reinterpret_cast<bf16x8*>(Kt + TrImg<DKP>::off(r, c)) = vk[i];
+        }
+      }
+    } else {
+      stage<DK, DKP, true, true>(p.q, p.ldq, b, h, Lq, Lqp, Qr, KPITCH, Qt);
+      stage<DK, DKP, true, true>(p.k, p.ldk, b, h, Lk, Lkp, Kr, KPITCH, Kt);
+      stage<DK, DKP, true, false>(p.v, p.ldv, b, h, Lk, Lkp, Vr, KPITCH, nullptr);
+      stage<DK, DKP, true, true>(p.dctx, p.lddo, b, h, Lq, Lqp, dOr, KPITCH, dOt);
+    }
+  }
   // delta[q] = dO[q,:] . O[q,:] and the row's log-sum-exp: 4 lanes per row with 8-byte loads, all rows of the block in
   // flight at once (one row per wave at a time made this ~20 dependent global round trips, most of the kernel's time)
   for (int r0 = 0; r0 < Lqp; r0 += 64) {
@@ -249,7 +290,20 @@ __global__ __launch_bounds__(256) void t5_attn_bwd_mfma(AttnMP p) {
     f32x4 acc[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // position-bias values of the NEXT key pair are fetched while the current one is computed (clamped addresses)
+    auto load_bias_a = [&](int sidx, f32x4 (&bb)[2]) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = (2 * sidx + u) * 16 + g * 4 + r;
+          bb[u][r] = brow ? brow[key < Lk ? key : Lk - 1] : 0.f;
+        }
+    };
+    f32x4 bcur[2], bnxt[2];
+    load_bias_a(0, bcur);
     for (int sidx = 0; sidx < NK / 2; ++sidx) {
+      if (sidx + 1 < NK / 2) load_bias_a(sidx + 1, bnxt);
       f32x4 ds2[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -265,8 +319,7 @@ __global__ __launch_bounds__(256) void t5_attn_bwd_mfma(AttnMP p) {
           const int key = t * 16 + g * 4 + r;
           float dsv = 0.f;
           if (key < Lk && q < Lq && !(p.causal && key > q)) {
-            float x = st[r];
-            if (brow) x += brow[key];
+            const float x = st[r] + bcur[u][r];
             const float pr = __expf(x - lq);
             dsv = pr * (dpt[r] * drop_mult32(dc, (uint32_t)q * (uint32_t)Lk + key) - dq_);
             if (dbrow) atomicAdd(dbrow + key, dsv);
@@ -281,6 +334,7 @@ __global__ __launch_bounds__(256) void t5_attn_bwd_mfma(AttnMP p) {
       }
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DKP>(Kt, sidx * 32, dt * 16, lane), dsf, acc[dt], 0, 0, 0);
+      bcur[0] = bnxt[0]; bcur[1] = bnxt[1];
     }
     if (q < Lq) {
 #pragma unroll
@@ -301,7 +355,19 @@ __global__ __launch_bounds__(256) void t5_attn_bwd_mfma(AttnMP p) {
     f32x4 av[DT], ak[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) { av[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; ak[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    auto load_bias_b = [&](int sidx, f32x4 (&bb)[2]) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = (2 * sidx + u) * 16 + g * 4 + r;
+          bb[u][r] = p.bias ? p.bias[((long)h * Lq + (q < Lq ? q : Lq - 1)) * Lk + (key < Lk ? key : Lk - 1)] : 0.f;
+        }
+    };
+    f32x4 bcur[2], bnxt[2];
+    load_bias_b(0, bcur);
     for (int sidx = 0; sidx < NQ / 2; ++sidx) {
+      if (sidx + 1 < NQ / 2) load_bias_b(sidx + 1, bnxt);
       f32x4 pd2[2], ds2[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -318,8 +384,7 @@ __global__ __launch_bounds__(256) void t5_attn_bwd_mfma(AttnMP p) {
           const int q = qt * 16 + g * 4 + r;
           float pdv = 0.f, dsv = 0.f;
           if (key < Lk && q < Lq && !(p.causal && key > q)) {
-            float x = st[r];
-            if (p.bias) x += p.bias[((long)h * Lq + q) * Lk + key];
+            const float x = st[r] + bcur[u][r];
             const float pr = __expf(x - lses[q]);
             const float mlt = drop_mult32(dc, (uint32_t)q * (uint32_t)Lk + key);
             pdv = pr * mlt;
@@ -334,6 +399,7 @@ __global__ __launch_bounds__(256) void t5_attn_bwd_mfma(AttnMP p) {
         av[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DKP>(dOt, sidx * 32, dt * 16, lane), pdf, av[dt], 0, 0, 0);
         ak[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DKP>(Qt, sidx * 32, dt * 16, lane), dsf, ak[dt], 0, 0, 0);
       }
+      bcur[0] = bnxt[0]; bcur[1] = bnxt[1];
     }
     if (key < Lk) {
 #pragma unroll

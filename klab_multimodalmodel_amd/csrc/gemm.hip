@@ -227,7 +227,7 @@ __device__ __forceinline__ void staged_epilogue_v(const GemmP& p, f32x4 (&acc)[M
         if constexpr (GEN) {
           if (p.bias) x += p.bias[nc];
           if (p.act == KLAB_ACT_RELU) x = fmaxf(x, 0.f);
-          else if (p.act == KLAB_ACT_GELU) x = gelu_erf(x);
+          else if (p.act == KLAB_ACT_GELU) x = gelu_for<T>(x);
           if (p.aux) {
             const float a = to_f32(reinterpret_cast<const T*>(p.aux)[(long)mc * p.ldaux + nc]);
             if (p.aux_mode == KLAB_AUX_NONZERO) x = (a != 0.f) ? x * p.aux_scale : 0.f;
@@ -241,7 +241,7 @@ __device__ __forceinline__ void staged_epilogue_v(const GemmP& p, f32x4 (&acc)[M
         } else {
           if constexpr (FLAGS & EF_BIAS) x += p.bias[nc];
           if constexpr (FLAGS & EF_RELU) x = fmaxf(x, 0.f);
-          if constexpr (FLAGS & EF_GELU) x = gelu_erf(x);
+          if constexpr (FLAGS & EF_GELU) x = gelu_for<T>(x);
           if constexpr (FLAGS & EF_AUXNZ) {
             const float a = to_f32(reinterpret_cast<const T*>(p.aux)[(long)mc * p.ldaux + nc]);
             x = (a != 0.f) ? x * p.aux_scale : 0.f;

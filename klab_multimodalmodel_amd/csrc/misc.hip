@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ x, 
     VT v = *reinterpret_cast<const VT*>(x + g * VEC);
     VT o;
 #pragma unroll
-    for (int u = 0; u < VEC; ++u) o[u] = from_f32<T>(gelu_erf(to_f32(v[u])));
+    for (int u = 0; u < VEC; ++u) o[u] = from_f32<T>(gelu_for<T>(to_f32(v[u])));
     *reinterpret_cast<VT*>(y + g * VEC) = o;
   }
 }

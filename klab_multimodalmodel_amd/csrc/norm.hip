@@ -151,14 +151,22 @@ __global__ __launch_bounds__(1024) void rmsnorm_bwd_dw_kernel(const float* __res
     const long yrow = remap_row(row, grp, grp_stride, off);
     const float* dyr = dy + yrow * d;
     const float r = rstd[row];
-    f32x4 v[SLOTS], e[SLOTS];
+    f32x4 v[SLOTS], e[SLOTS], q[SLOTS];
     float dot = 0.f;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {  // every load of the row goes out before the first use (one memory round trip)
+      const int c = lane * 4 + s * 256;
+      q[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < d) {
+        v[s] = *reinterpret_cast<const f32x4*>(xr + c);
+        e[s] = *reinterpret_cast<const f32x4*>(dyr + c);
+        if (dres) q[s] = *reinterpret_cast<const f32x4*>(dres + row * d + c);
+      }
+    }
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
       const int c = lane * 4 + s * 256;
       if (c < d) {
-        v[s] = *reinterpret_cast<const f32x4*>(xr + c);
-        e[s] = *reinterpret_cast<const f32x4*>(dyr + c);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           e[s][i] *= drop_mult(dcy, (uint64_t)yrow * d + c + i);
@@ -175,12 +183,7 @@ __global__ __launch_bounds__(1024) void rmsnorm_bwd_dw_kernel(const float* __res
       if (c < d) {
         float o[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = r * g[s][i] * e[s][i] - v[s][i] * k;
-        if (dres) {
-          f32x4 q = *reinterpret_cast<const f32x4*>(dres + row * d + c);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) o[i] += q[i];
-        }
+        for (int i = 0; i < 4; ++i) o[i] = r * g[s][i] * e[s][i] - v[s][i] * k + q[s][i];
         if (dx) store4<float>(dx + row * d + c, o[0], o[1], o[2], o[3]);
         if (dxt) {
 #pragma unroll
