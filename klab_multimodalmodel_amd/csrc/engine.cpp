@@ -602,12 +602,23 @@ int main_after_side(const Ctx& c) {
   RC((int)hipEventRecord(ev, e->side));
   return (int)hipStreamWaitEvent(c.s, ev, 0);
 }
-// weight gradient on the side stream: its operands were produced on the main stream just before this call
-int wgrad_side(const Ctx& c, const void* dy, long lddy, const void* x, long ldx, int M, int N, int K, float* dw) {
-  RC(side_after_main(c));
-  Ctx cs{c.e, c.e->side, c.dt, c.es};
-  return linear_wgrad(cs, dy, lddy, x, ldx, M, N, K, dw);
-}
+// Weight gradients on the side stream.  Their operands live in per-sub-layer buffers that are not rewritten inside a
+// backward segment, so they may run any time after the producer: they are queued here and released in batches with ONE
+// main->side event per layer (an event record costs the main queue ~6 us; one per weight gradient left ~40 us of
+// bubbles in every layer's critical path).
+struct PendingWgrad { const void* dy; long lddy; const void* x; long ldx; int M, N, K; float* dw; };
+struct WgradQueue {
+  std::vector<PendingWgrad> q;
+  void push(const void* dy, long lddy, const void* x, long ldx, int M, int N, int K, float* dw) { q.push_back({dy, lddy, x, ldx, M, N, K, dw}); }
+  int flush(const Ctx& c) {
+    if (q.empty()) return 0;
+    RC(side_after_main(c));
+    Ctx cs{c.e, c.e->side, c.dt, c.es};
+    for (const PendingWgrad& w : q) RC(linear_wgrad(cs, w.dy, w.lddy, w.x, w.ldx, w.M, w.N, w.K, w.dw));
+    q.clear();
+    return 0;
+  }
+};
 
 // ------------------------------------------------------------------------------------------------
 // T5 stack backward.  In: dxn = d loss / d (final-norm output) in f32 [M,d].  Out: dh_cur = d loss / d h[0].
@@ -627,6 +638,7 @@ int t5_stack_backward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Pa
   auto G = [&](int pi) { return Gflat + P[pi].grad_off; };
   const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
   int dy_i = 0, deferred = 0;
+  WgradQueue wq;
   auto next_dy = [&]() { return e->dy_pool[dy_i++ % e->dy_pool.size()]; };
   RC(hipMemsetAsync(s.dbias, 0, (size_t)H * Lq * Lq * 4, c.s));
   // final norm: y = drop(norm(h[j])); previous sub-layer output dropout = FFN_OUT of the last layer
@@ -640,13 +652,13 @@ int t5_stack_backward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Pa
     void* dqkv = e->dqkv_pool[i];
     // ---------------- FFN ----------------
     --j;
-    RC(wgrad_side(c, dy, d, b.hmid, ff, M, d, ff, G(l.wo)));
+    wq.push(dy, d, b.hmid, ff, M, d, ff, G(l.wo));
     {
       klab_gemm_args g = G0(c, M, ff, d, dy, d, 1, woff(c, P[l.wo].warena_off), ff, 0, dhmid, ff, c.dt);
       g.aux = b.hmid; g.ldaux = ff; g.aux_mode = KLAB_AUX_NONZERO; g.aux_scale = inv_keep;
       RC(klab_gemm(&g, c.ws()));
     }
-    RC(wgrad_side(c, dhmid, ff, b.xn3, d, M, ff, d, G(l.wi)));
+    wq.push(dhmid, ff, b.xn3, d, M, ff, d, G(l.wi));
     RC(linear_dgrad(c, dhmid, ff, M, ff, P[l.wi].warena_off, d, e->dxn, KLAB_F32));
     {
       const uint32_t tprev = dec ? tag_of(stack_id, i, SITE_XOUT) : tag_of(stack_id, i, SITE_ATTN_OUT);
@@ -658,7 +670,7 @@ int t5_stack_backward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Pa
     if (dec) {  // ---------------- cross attention ----------------
       --j;
       void* dqc = e->dqc_pool[i];
-      RC(wgrad_side(c, dy, d, b.ctx2, inner, M, d, inner, G(l.co)));
+      wq.push(dy, d, b.ctx2, inner, M, d, inner, G(l.co));
       RC(linear_dgrad(c, dy, d, M, d, P[l.co].warena_off, inner, e->dctx, c.dt));
       klab_attn_args a;
       memset(&a, 0, sizeof(a));
@@ -671,7 +683,7 @@ int t5_stack_backward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Pa
       a.dk_out = eoff(c, dkv_all, (long)i * 2 * inner); a.lddk = kv_ld;
       a.dv = eoff(c, dkv_all, (long)i * 2 * inner + inner); a.lddv = kv_ld;
       RC(klab_t5_attn_bwd(&a, c.ws()));
-      RC(wgrad_side(c, dqc, inner, b.xn2, d, M, inner, d, G(l.cq)));
+      wq.push(dqc, inner, b.xn2, d, M, inner, d, G(l.cq));
       RC(linear_dgrad(c, dqc, inner, M, inner, P[l.cq].warena_off, d, e->dxn, KLAB_F32));
       dy = next_dy();
       RC(klab_rmsnorm_bwd(e->dxn, s.h[j], W[l.ln1], b.rstd2, dh_cur, dh_oth, dy, c.dt, G(l.ln1), M, d, 0, 0, 0, 0.f, 0, p,
@@ -680,7 +692,7 @@ int t5_stack_backward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Pa
     }
     // ---------------- self attention ----------------
     --j;
-    RC(wgrad_side(c, dy, d, b.ctx, inner, M, d, inner, G(l.o)));
+    wq.push(dy, d, b.ctx, inner, M, d, inner, G(l.o));
     RC(linear_dgrad(c, dy, d, M, d, P[l.o].warena_off, inner, e->dctx, c.dt));
     {
       klab_attn_args a;
@@ -702,7 +714,7 @@ int t5_stack_backward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Pa
       if (arc == KLAB_ERR_UNSUPPORTED) { a.ds_defer = 0; a.ds_ws = nullptr; arc = klab_t5_attn_bwd(&a, c.ws()); }
       RC(arc);
     }
-    RC(wgrad_side(c, dqkv, 3 * inner, b.xn1, d, M, 3 * inner, d, G(l.q)));  // q|k|v grads are adjacent
+    wq.push(dqkv, 3 * inner, b.xn1, d, M, 3 * inner, d, G(l.q));  // q|k|v grads are adjacent
     RC(linear_dgrad(c, dqkv, 3 * inner, M, 3 * inner, P[l.q].warena_off, d, e->dxn, KLAB_F32));
     {
       const bool first = (i == 0);
@@ -711,6 +723,7 @@ int t5_stack_backward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Pa
                           first ? 0.f : p, first ? 0u : tag_of(stack_id, i - 1, SITE_FFN_OUT), e->seed_dev, c.ws()));
       float* t = dh_cur; dh_cur = dh_oth; dh_oth = t;
     }
+    RC(wq.flush(c));  // this layer's weight gradients: one event, then they overlap the next layer's chain
   }
   if (deferred) RC(klab_dbias_reduce(e->ds_ws, c.dt, s.dbias, deferred * B, H, Lq, Lq, c.ws()));
   RC(klab_relbias_bwd(s.dbias, s.bucket, G(L[0].relb), H, Lq, Lq, cfg.rel_buckets, c.ws()));
