@@ -183,10 +183,24 @@ __device__ __forceinline__ void tile_of_block(const GemmP& p, int BM, int BN, in
   const int xcd = bid & 7, idx = bid >> 3;
   const int q = nwg >> 3, r = nwg & 7;
   const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  // The smaller operand's tiles vary fastest (consecutive workgroups of an XCD share the other operand's panel), in
+  // GROUPS whose panels fit in half of the XCD's 4 MiB L2: walking all 32 m-tiles of the LM head (4.2 MB of A) before
+  // the next n-tile evicted A on every pass -- PMC showed ~10x the algorithmic read bytes leaving L2.
+  const int kbytes = (p.K / (p.splits > 0 ? p.splits : 1)) * 2;
   if ((long)p.M <= (long)p.N) {  // A (M x K) is the smaller operand: m fastest
-    bm0 = (lin % tiles_m) * BM; bn0 = (lin / tiles_m) * BN;
+    int G = (2 << 20) / (BM * kbytes);
+    G = (G < 8 || G > tiles_m || (p.ablate & 32)) ? tiles_m : G;  // groups narrower than 8 tiles would re-read the streamed operand too often
+    const int per_group = G * tiles_n, full = tiles_m / G;
+    const int g = lin / per_group;
+    if (g < full) { const int rem = lin - g * per_group; bm0 = (int)(g * G + rem % G) * BM; bn0 = (int)(rem / G) * BN; }
+    else { const int rem = lin - full * per_group, gm = tiles_m - full * G; bm0 = (int)(full * G + rem % gm) * BM; bn0 = (int)(rem / gm) * BN; }
   } else {
-    bn0 = (lin % tiles_n) * BN; bm0 = (lin / tiles_n) * BM;
+    int G = (2 << 20) / (BN * kbytes);
+    G = (G < 8 || G > tiles_n || (p.ablate & 32)) ? tiles_n : G;
+    const int per_group = G * tiles_m, full = tiles_n / G;
+    const int g = lin / per_group;
+    if (g < full) { const int rem = lin - g * per_group; bn0 = (int)(g * G + rem % G) * BN; bm0 = (int)(rem / G) * BM; }
+    else { const int rem = lin - full * per_group, gn = tiles_n - full * G; bn0 = (int)(full * G + rem % gn) * BN; bm0 = (int)(rem / gn) * BM; }
   }
 }
 
