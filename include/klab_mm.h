@@ -166,6 +166,13 @@ int klab_convert(const float* x, void* y, int dtype, long n, float scale, void* 
 int klab_add_f32(float* y, const float* x, long n, void* stream);
 
 int klab_gelu_fwd(const void* x, void* y, int dtype, long n, void* stream);
+/* Frozen-tower (forward-only) fusion of the MLP half of a Swin-V2 block, HF/swinv2:539-563 + 697-702:
+ *   out[M,C] = shortcut + LayerNorm(fc2(GELU(fc1(x) + b1)) + b2) * gamma + beta,  outt = bf16(out) (optional)
+ * x [M,C], w1 [4C,C], w2 [C,4C] in `dtype` (bf16 only), everything else f32.  C in {64, 128}; other widths return
+ * KLAB_ERR_UNSUPPORTED and the caller keeps the three-kernel path (klab_gemm x2 + klab_layernorm_fwd). */
+int klab_swin_mlp_fused(const void* x, const float* shortcut, const void* w1, const float* b1, const void* w2, const float* b2,
+                        const float* gamma, const float* beta, float* out, void* outt, int dtype, int M, int C, float eps,
+                        void* stream);
 int klab_swin_cpb_bias_bwd(const float* dbias, const float* bias, const int* index, const float* coords, const float* hidden,
                            const float* w0, const float* w2, float* dtable, float* dw0, float* db0, float* dw2, int ntab, int n,
                            int heads, int nhidden, void* stream);

@@ -773,6 +773,12 @@ int swin_forward(const Ctx& c, const float* pixels, float p_in, bool refresh_bia
         RC(linear_fwd(c, q.h1t, M, C, P[ix.f1w].warena_off, F, q.z, F, c.dt, W[ix.f1b]));
         RC(klab_gelu_fwd(q.z, q.a, c.dt, (long)M * F, c.ws()));
       } else {
+        // frozen tower, narrow stage: fc1 + GELU + fc2 + LayerNorm + residual in one kernel (the hidden layer stays on chip)
+        static const bool fused_mlp = [] { const char* v = getenv("KLAB_SWIN_FUSED_MLP"); return !v || atoi(v) != 0; }();
+        const int frc = !fused_mlp ? KLAB_ERR_UNSUPPORTED : klab_swin_mlp_fused(q.h1t, q.h1, woff(c, P[ix.f1w].warena_off), W[ix.f1b], woff(c, P[ix.f2w].warena_off), W[ix.f2b],
+                                            W[ix.ln2w], W[ix.ln2b], q.h2, q.h2t, c.dt, M, C, s.ln_eps, c.ws());
+        if (frc == 0) { x = q.h2; xt = q.h2t; continue; }
+        if (frc != KLAB_ERR_UNSUPPORTED) return frc;
         RC(linear_fwd(c, q.h1t, M, C, P[ix.f1w].warena_off, F, q.a, F, c.dt, W[ix.f1b], KLAB_ACT_GELU));
       }
       RC(linear_fwd(c, q.a, M, F, P[ix.f2w].warena_off, C, q.fo, C, c.dt, W[ix.f2b]));

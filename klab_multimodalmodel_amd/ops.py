@@ -67,6 +67,16 @@ def layernorm_fwd(y, gamma, beta, shortcut=None, out=None, outt=None, mean=None,
                                    L.stream_ptr()), "klab_layernorm_fwd")
 
 
+def swin_mlp_fused(x, shortcut, w1, b1, w2, b2, gamma, beta, out, outt=None, eps=1e-5):
+    """out = shortcut + LN(fc2(GELU(fc1(x)+b1))+b2)*gamma+beta (frozen Swin-V2 MLP half, C in {64,128}); raises
+    NotImplementedError for other widths (HF/swinv2:539-563, 697-702)."""
+    lib = L.load()
+    M, Cc = x.shape
+    L.check(lib.klab_swin_mlp_fused(x.data_ptr(), shortcut.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                    gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), L.ptr(outt), L.dtype_code(x.dtype), M, Cc, eps,
+                                    L.stream_ptr()), "klab_swin_mlp_fused")
+
+
 def layernorm_bwd(dout, y, gamma, mean, rstd, dy=None, dgamma=None, dbeta=None, grp=0, grp_stride=0, off=0, drop_p=0.0,
                   seed=None, tag=0):
     lib = L.load()

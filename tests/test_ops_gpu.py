@@ -464,3 +464,32 @@ def test_colsum_and_convert(ops, dt):
     y = torch.empty(64, 16, device="cuda", dtype=dt)
     ops.convert(dev(x), y, 0.5)
     assert rel_l2(y.float().cpu(), 0.5 * x) < (1e-7 if dt == torch.float32 else 4e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,Cc", [(300, 64), (128, 64), (1000, 128), (77, 128)])
+def test_swin_mlp_fused_matches_torch(ops, M, Cc):
+    """Fused frozen-tower MLP half == fc1 -> erf-GELU -> fc2 -> LayerNorm -> + shortcut in fp32 torch (HF/swinv2:539-563,697-702)
+    on the same bf16-rounded operands; tolerance = bf16 rounding of the hidden activations."""
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(M, Cc, generator=g)).to(torch.bfloat16)
+    sc = torch.randn(M, Cc, generator=g)
+    w1 = (torch.randn(4 * Cc, Cc, generator=g) / Cc ** 0.5).to(torch.bfloat16)
+    w2 = (torch.randn(Cc, 4 * Cc, generator=g) / (4 * Cc) ** 0.5).to(torch.bfloat16)
+    b1, b2 = torch.randn(4 * Cc, generator=g) * 0.1, torch.randn(Cc, generator=g) * 0.1
+    gm, bt = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.1
+    h = F.gelu(x.float() @ w1.float().t() + b1).to(torch.bfloat16).float()
+    y = h @ w2.float().t() + b2
+    ref = sc + F.layer_norm(y, (Cc,), gm, bt, 1e-5)
+    out = torch.empty(M, Cc, device="cuda")
+    outt = torch.empty(M, Cc, device="cuda", dtype=torch.bfloat16)
+    ops.swin_mlp_fused(dev(x), dev(sc), dev(w1), dev(b1), dev(w2), dev(b2), dev(gm), dev(bt), out, outt, eps=1e-5)
+    assert rel_l2(out.cpu(), ref) < 4e-3
+    assert rel_l2(outt.float().cpu(), ref) < 8e-3
+    if Cc == 64:
+        with pytest.raises(NotImplementedError):
+            bad = torch.zeros(8, 256, device="cuda", dtype=torch.bfloat16)
+            ops.swin_mlp_fused(bad, torch.zeros(8, 256, device="cuda"), torch.zeros(1024, 256, device="cuda", dtype=torch.bfloat16),
+                               torch.zeros(1024, device="cuda"), torch.zeros(256, 1024, device="cuda", dtype=torch.bfloat16),
+                               torch.zeros(256, device="cuda"), torch.ones(256, device="cuda"), torch.zeros(256, device="cuda"),
+                               torch.empty(8, 256, device="cuda"))
