@@ -159,6 +159,9 @@ int klab_relbias_bwd(const float* dbias, const int* bucket, float* dtable, int h
 int klab_ce_fwd(void* logits, long ld, int dtype, const long long* labels, int rows, int V, float* inv_n, float* loss_row,
                 float* loss, int write_grad, void* stream);
 int klab_im2col_patch(const float* pixels, void* out, int dtype, int B, int Cin, int Himg, int P, void* stream);
+/* same, rows of `ldo` >= Cin*P*P elements with the tail columns zero-filled (lets the patch-embedding GEMM run with K
+ * padded to a multiple of 32); P == 4 takes a one-thread-per-patch vector path */
+int klab_im2col_patch_ld(const float* pixels, void* out, int dtype, int B, int Cin, int Himg, int P, int ldo, void* stream);
 int klab_merge_gather(const float* x, void* out, int dtype, int B, int R, int C, void* stream);
 int klab_merge_scatter(const float* dmerged, float* dx, int B, int R, int C, void* stream);
 int klab_colsum(const void* dy, long ld, int dtype, int M, int N, float* out, void* stream);

@@ -387,7 +387,7 @@ size_t plan_workspace(klab_engine* e, void* base, int B, int Ls, int Lt) {
   e->pixels_buf = (float*)b.take((size_t)B * c.swin.in_ch * c.swin.image_size * c.swin.image_size * 4);
   e->src_buf = (long long*)b.take((size_t)B * Ls * 8);
   e->tgt_buf = (long long*)b.take((size_t)B * Lt * 8);
-  e->warena = b.take((size_t)e->warena_elems * es);
+  e->warena = b.take((size_t)(e->warena_elems + 64) * es);  // + slack: the patch-embedding GEMM reads K padded to 32 past a weight row
   e->farena = (float*)b.take((size_t)e->farena_elems * 4);
   e->cast_desc = b.take(sizeof(long) * 3 * 2 * (e->P[0].size() + e->P[1].size() + e->P[2].size() + 1));  // two groups
   e->fcast_desc = b.take(sizeof(long) * 3 * (e->P[0].size() + 1));
@@ -423,7 +423,7 @@ size_t plan_workspace(klab_engine* e, void* base, int B, int Ls, int Lt) {
   // ---- Swin ----
   const klab_swin_cfg& s = c.swin;
   const long T0 = (long)R0 * R0, M0 = (long)B * T0, K0 = (long)s.in_ch * s.patch * s.patch, C0 = s.embed_dim;
-  e->cols = b.take((size_t)M0 * K0 * es);
+  e->cols = b.take((size_t)M0 * ((K0 + 31) & ~31L) * es);  // rows padded to a multiple of 32 columns (bf16 LDS-DMA GEMM path)
   e->pe_out = b.take((size_t)M0 * C0 * es);
   e->pe_mean = (float*)b.take((size_t)M0 * 4); e->pe_rstd = (float*)b.take((size_t)M0 * 4);
   e->x0 = (float*)b.take((size_t)M0 * C0 * 4); e->x0t = b.take((size_t)M0 * C0 * es);
@@ -741,8 +741,16 @@ int swin_forward(const Ctx& c, const float* pixels, float p_in, bool refresh_bia
   const auto& W = e->W[0];
   const int B = e->B, R0 = s.image_size / s.patch, K0 = s.in_ch * s.patch * s.patch, C0 = s.embed_dim;
   const long M0 = (long)B * R0 * R0;
-  RC(klab_im2col_patch(pixels, e->cols, c.dt, B, s.in_ch, s.image_size, s.patch, c.ws()));
-  RC(linear_fwd(c, e->cols, (int)M0, K0, P[e->si.pew].warena_off, C0, e->pe_out, C0, c.dt, W[e->si.peb]));
+  // patch embedding (Conv2d k4 s4, HF/swinv2:281) = im2col + GEMM.  bf16: the rows are zero-padded from K0 = 48 to 64
+  // columns so that the GEMM takes the LDS-DMA path (K % 32 == 0); the weight rows keep their pitch of K0, the 16 extra
+  // columns read there are the next row's (finite) weights and meet zeros.
+  const int Kp = (c.dt == KLAB_BF16 && s.patch == 4) ? ((K0 + 31) & ~31) : K0;
+  RC(klab_im2col_patch_ld(pixels, e->cols, c.dt, B, s.in_ch, s.image_size, s.patch, Kp, c.ws()));
+  {
+    klab_gemm_args g = G0(c, (int)M0, C0, Kp, e->cols, Kp, 1, woff(c, P[e->si.pew].warena_off), K0, 1, e->pe_out, C0, c.dt);
+    g.bias = W[e->si.peb];
+    RC(klab_gemm(&g, c.ws()));
+  }
   RC(klab_layernorm_fwd(e->pe_out, c.dt, W[e->si.penw], W[e->si.penb], nullptr, e->x0, e->x0t, c.dt, e->pe_mean, e->pe_rstd, (int)M0, C0,
                         s.ln_eps, 0, 0, 0, 0.f, nullptr, 0, c.ws()));
   float* x = e->x0;
@@ -1323,7 +1331,7 @@ int swin_backward(const Ctx& c, const float* dh0, float p_in) {
   RC(klab_layernorm_bwd(dh, e->pe_out, c.dt, W[e->si.penw], e->pe_mean, e->pe_rstd, e->sdy, G(e->si.penw), G(e->si.penb), (int)M0, C0, 0, 0, 0,
                         0.f, nullptr, 0, c.ws()));
   RC(klab_colsum(e->sdy, C0, c.dt, (int)M0, C0, G(e->si.peb), c.ws()));
-  RC(linear_wgrad(c, e->sdy, C0, e->cols, K0, (int)M0, C0, K0, G(e->si.pew)));
+  RC(linear_wgrad(c, e->sdy, C0, e->cols, (c.dt == KLAB_BF16 && s.patch == 4) ? ((K0 + 31) & ~31) : K0, (int)M0, C0, K0, G(e->si.pew)));
   return 0;
 }
 

@@ -225,6 +225,38 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ p
   }
 }
 
+// P == 4 form: one thread per patch, Cin*4 independent 16-byte loads (a wave reads 64 neighbouring patches = 1 KiB
+// contiguous per load), 16-byte stores; columns [K, ldo) are zero-filled so the GEMM can run with K padded to 32.
+// (The element-per-thread form above gathered 4-byte pieces: 1.3 TB/s.)
+template <typename T>
+__global__ __launch_bounds__(256) void im2col4_kernel(const float* __restrict__ pix, T* __restrict__ out, int B, int Cin, int Himg, int ldo) {
+  const int R = Himg / 4;
+  const long npatch = (long)B * R * R;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < npatch; t += (long)gridDim.x * blockDim.x) {
+    const int x = t % R, y = (t / R) % R;
+    const long b = t / ((long)R * R);
+    T* o = out + t * ldo;
+    for (int c = 0; c < Cin; ++c) {
+      f32x4 v[4];
+#pragma unroll
+      for (int py = 0; py < 4; ++py) v[py] = *reinterpret_cast<const f32x4*>(pix + ((b * Cin + c) * Himg + (y * 4 + py)) * Himg + x * 4);
+      if constexpr (sizeof(T) == 2) {
+        *reinterpret_cast<bf16x8*>(o + c * 16) = bf16x8{(bf16_t)v[0][0], (bf16_t)v[0][1], (bf16_t)v[0][2], (bf16_t)v[0][3],
+                                                        (bf16_t)v[1][0], (bf16_t)v[1][1], (bf16_t)v[1][2], (bf16_t)v[1][3]};
+        *reinterpret_cast<bf16x8*>(o + c * 16 + 8) = bf16x8{(bf16_t)v[2][0], (bf16_t)v[2][1], (bf16_t)v[2][2], (bf16_t)v[2][3],
+                                                            (bf16_t)v[3][0], (bf16_t)v[3][1], (bf16_t)v[3][2], (bf16_t)v[3][3]};
+      } else {
+#pragma unroll
+        for (int py = 0; py < 4; ++py) *reinterpret_cast<f32x4*>(o + c * 16 + py * 4) = v[py];
+      }
+    }
+    for (int k = Cin * 16; k < ldo; k += 8) {  // ldo % 8 == 0
+      if constexpr (sizeof(T) == 2) *reinterpret_cast<bf16x8*>(o + k) = bf16x8{};
+      else { *reinterpret_cast<f32x4*>(o + k) = f32x4{0.f, 0.f, 0.f, 0.f}; *reinterpret_cast<f32x4*>(o + k + 4) = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
+  }
+}
+
 // ---- Swin patch merging gather (HF/swinv2:342-351): [B,R,R,C] -> [B,(R/2)^2, 4C] in the order
 //      (0,0),(1,0),(0,1),(1,1) (row offset, col offset) ------------------------------------------
 template <typename T>
@@ -389,6 +421,20 @@ extern "C" int klab_im2col_patch(const float* pixels, void* out, int dtype, int 
   hipStream_t s = (hipStream_t)stream;
   if (dtype == KLAB_BF16) hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(stream_grid(total)), dim3(256), 0, s, pixels, (bf16_t*)out, B, Cin, Himg, P);
   else hipLaunchKernelGGL(im2col_kernel<float>, dim3(stream_grid(total)), dim3(256), 0, s, pixels, (float*)out, B, Cin, Himg, P);
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+
+extern "C" int klab_im2col_patch_ld(const float* pixels, void* out, int dtype, int B, int Cin, int Himg, int P, int ldo, void* stream) {
+  if (!pixels || !out || Himg % P || ldo < Cin * P * P) return KLAB_ERR_BADARG;
+  if (P != 4 || (Himg & 3) || (ldo & 7) || ((uintptr_t)pixels & 15) || ((uintptr_t)out & 15)) {
+    if (ldo == Cin * P * P) return klab_im2col_patch(pixels, out, dtype, B, Cin, Himg, P, stream);
+    return KLAB_ERR_UNSUPPORTED;
+  }
+  const long npatch = (long)B * (Himg / 4) * (Himg / 4);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == KLAB_BF16) hipLaunchKernelGGL(im2col4_kernel<bf16_t>, dim3(stream_grid(npatch)), dim3(256), 0, s, pixels, (bf16_t*)out, B, Cin, Himg, ldo);
+  else hipLaunchKernelGGL(im2col4_kernel<float>, dim3(stream_grid(npatch)), dim3(256), 0, s, pixels, (float*)out, B, Cin, Himg, ldo);
   KLAB_LAUNCH_CHECK();
   return KLAB_OK;
 }

@@ -190,8 +190,13 @@ def relbias_bwd(dbias, bucket, dtable):
 def im2col_patch(pixels, out, P):
     lib = L.load()
     B, Cin, Himg, _ = pixels.shape
-    L.check(lib.klab_im2col_patch(pixels.data_ptr(), out.data_ptr(), L.dtype_code(out.dtype), B, Cin, Himg, P, L.stream_ptr()),
-            "klab_im2col_patch")
+    ldo = out.shape[-1]
+    if ldo == Cin * P * P:
+        L.check(lib.klab_im2col_patch(pixels.data_ptr(), out.data_ptr(), L.dtype_code(out.dtype), B, Cin, Himg, P, L.stream_ptr()),
+                "klab_im2col_patch")
+    else:  # padded rows: tail columns are zero-filled
+        L.check(lib.klab_im2col_patch_ld(pixels.data_ptr(), out.data_ptr(), L.dtype_code(out.dtype), B, Cin, Himg, P, ldo, L.stream_ptr()),
+                "klab_im2col_patch_ld")
 
 
 def merge_gather(x, out, *, B, R, C):
