@@ -210,7 +210,11 @@ __device__ __forceinline__ void tile_of_block(const GemmP& p, int BM, int BN, in
 // consecutive lanes on consecutive addresses.  (Storing straight from the MFMA layout wrote 32-B pieces of
 // 16 different rows per instruction: partial-line writes were the bound of every short-K GEMM.)
 // Caller guarantees that all waves are past their last LDS read of the main loop (a barrier).
-enum : int { EF_BIAS = 1, EF_RELU = 2, EF_GELU = 4, EF_AUXNZ = 8, EF_DGELU = 16, EF_DROP = 32, EF_RES = 64, EF_GENERIC = 128 };
+enum : int { EF_BIAS = 1, EF_RELU = 2, EF_GELU = 4, EF_AUXNZ = 8, EF_DGELU = 16, EF_DROP = 32, EF_RES = 64, EF_GENERIC = 128,
+             // the same two features applied while the staged tile is streamed out (16 B per lane, row-contiguous: coalesced
+             // reads of the mask / residual) instead of in the MFMA layout (2- and 4-byte reads of 16 rows per instruction:
+             // the relu-mask dgrad ran at 38 us against 16 us for the plain GEMM); chosen on the host when dtypes/alignment allow
+             EF_AUXNZ_CO = 256, EF_RES_CO = 512 };
 
 // FLAGS is a compile-time feature set: each variant contains only the code of its features, fully unrolled over the
 // lane's 16-64 accumulator elements (~0.3-2 K instructions).  One big run-time-flagged body (every feature x every
@@ -260,6 +264,7 @@ __device__ __forceinline__ void staged_epilogue_v(const GemmP& p, f32x4 (&acc)[M
             const float a = to_f32(reinterpret_cast<const T*>(p.aux)[(long)mc * p.ldaux + nc]);
             x = (a != 0.f) ? x * p.aux_scale : 0.f;
           }
+          if constexpr (FLAGS & EF_AUXNZ_CO) x *= p.aux_scale;  // the zero mask itself is applied at copy-out
           if constexpr (FLAGS & EF_DGELU) x *= gelu_erf_grad(to_f32(reinterpret_cast<const T*>(p.aux)[(long)mc * p.ldaux + nc]));
           if constexpr (FLAGS & EF_DROP) x *= drop_mult(dc, (uint64_t)mc * (uint64_t)p.N + (uint64_t)nc);
           if constexpr (FLAGS & EF_RES) {
@@ -276,7 +281,7 @@ __device__ __forceinline__ void staged_epilogue_v(const GemmP& p, f32x4 (&acc)[M
   }
 }
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int CO = 0>
 __device__ __forceinline__ void copy_out_tile(const GemmP& p, const char* smem, int bm0, int bn0, int tid) {
   const bool f32out = p.c_f32 || sizeof(T) == 4;
   const int pitchB = f32out ? (BN + 4) * 4 : (BN + 8) * 2;
@@ -292,6 +297,21 @@ __device__ __forceinline__ void copy_out_tile(const GemmP& p, const char* smem, 
     if (m >= p.M || n >= p.N) continue;
     const char* src = smem + row * pitchB + cc * 16;
     char* dst = Cb + ((long)m * p.ldc + n) * esz;
+    if constexpr (CO & EF_AUXNZ_CO) {  // bf16 tile, bf16 mask source, vector path guaranteed by the host
+      bf16x8 nv = *reinterpret_cast<const bf16x8*>(src);
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.aux) + (long)m * p.ldaux + n);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) nv[u] = ((float)a[u] != 0.f) ? nv[u] : (bf16_t)0.f;
+      *reinterpret_cast<bf16x8*>(dst) = nv;
+      continue;
+    }
+    if constexpr (CO & EF_RES_CO) {    // f32 tile + f32 residual, vector path guaranteed by the host
+      f32x4 val = *reinterpret_cast<const f32x4*>(src);
+      const f32x4 r = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.residual) + (long)m * p.ldr + n);
+      val[0] += r[0]; val[1] += r[1]; val[2] += r[2]; val[3] += r[3];
+      *reinterpret_cast<f32x4*>(dst) = val;
+      continue;
+    }
     if (vec_ok) {
       f32x4 val = *reinterpret_cast<const f32x4*>(src);
       if (p.accumulate) {
@@ -340,11 +360,18 @@ __device__ __forceinline__ void staged_epilogue(const GemmP& p, f32x4 (&acc)[MI]
     case EF_DROP | EF_RES: KLAB_EPI(EF_DROP | EF_RES); break;
     case EF_AUXNZ: KLAB_EPI(EF_AUXNZ); break;
     case EF_DGELU: KLAB_EPI(EF_DGELU); break;
+    case EF_AUXNZ_CO: KLAB_EPI(EF_AUXNZ_CO); break;
+    case EF_RES_CO: KLAB_EPI(0); break;
+    case EF_DROP | EF_RES_CO: KLAB_EPI(EF_DROP); break;
     default: KLAB_EPI(EF_GENERIC); break;
   }
 #undef KLAB_EPI
   __syncthreads();
   if (p.ablate & 8) return;
+  if constexpr (sizeof(T) == 2) {
+    if (p.epi == EF_AUXNZ_CO) { copy_out_tile<T, BM, BN, EF_AUXNZ_CO>(p, smem, bm0, bn0, tid); return; }
+  }
+  if (p.epi == EF_RES_CO || p.epi == (EF_DROP | EF_RES_CO)) { copy_out_tile<T, BM, BN, EF_RES_CO>(p, smem, bm0, bn0, tid); return; }
   copy_out_tile<T, BM, BN>(p, smem, bm0, bn0, tid);
 }
 template <int BM, int BN> constexpr int epilogue_lds_bytes(bool f32out) { return f32out ? BM * (BN + 4) * 4 : BM * (BN + 8) * 2; }
@@ -890,6 +917,14 @@ extern "C" int klab_gemm(const klab_gemm_args* a, void* stream) {
     if (a->aux && a->aux_mode == KLAB_AUX_DGELU) f |= EF_DGELU;
     if (a->drop_p > 0.f && a->seed_dev) f |= EF_DROP;
     if (a->residual) f |= EF_RES;
+    // copy-out forms (see EF_*_CO): only the exact flag sets that have a variant, and only when every access is a whole
+    // aligned 16-byte vector and nothing is accumulated into C
+    if (!a->accumulate && a->dtype == KLAB_BF16) {
+      if (f == EF_AUXNZ && a->c_dtype == KLAB_BF16 && !(a->N & 7) && !(a->ldc & 7) && !(a->ldaux & 7) && !((uintptr_t)a->aux & 15)) f = EF_AUXNZ_CO;
+      if ((f == EF_RES || f == (EF_DROP | EF_RES)) && a->c_dtype == KLAB_F32 && a->r_dtype == KLAB_F32 && !(a->N & 3) && !(a->ldc & 3) &&
+          !(a->ldr & 3) && !((uintptr_t)a->residual & 15))
+        f = (f & ~EF_RES) | EF_RES_CO;
+    }
     p.epi = f;  // combinations without a dedicated variant fall into the generic body (switch default)
   }
   {
