@@ -160,48 +160,66 @@ __global__ __launch_bounds__(64) void swin_attn_fwd_mfma32(SwinAttnP p) {
   const int wy = win / nWr, wx = win % nWr;
   const bf16_t* qkv = reinterpret_cast<const bf16_t*>(p.qkv);
   const long ld = 3L * C;
-  {  // stage key/value row `lane`
-    const int j = lane;
-    bf16x8 kc[4] = {}, vc[4] = {};
-    int t = 0, rg = -1;
-    if (j < n) {
-      const int ys = wy * w + j / w, xs = wx * w + j % w;
-      const int y = (ys + p.shift) % R, x = (xs + p.shift) % R;
-      t = (b * R + y) * R + x;
-      rg = p.shift > 0 ? swin_region(ys, R, w, p.shift) * 3 + swin_region(xs, R, w, p.shift) : 0;
-      const bf16_t* kr = qkv + (long)t * ld + C + h * HD;
-      const bf16_t* vr = qkv + (long)t * ld + 2 * C + h * HD;
+  {  // stage keys / values: 4 lanes per token row (16 B each), 16 rows per pass -> every load instruction reads 16 whole
+     // 64-byte head slices (one lane per row touched 49 different cache lines with 16 B each)
+    const int sub = lane & 3, r4 = lane >> 2;
+    bf16x8 kc[4], vc[4];
+    int tk[4], rgs[4];
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int j = ps * 16 + r4;
+      kc[ps] = bf16x8{}; vc[ps] = bf16x8{};
+      tk[ps] = 0; rgs[ps] = -1;
+      if (j < n) {
+        const int ys = wy * w + j / w, xs = wx * w + j % w;
+        const int y = (ys + p.shift) % R, x = (xs + p.shift) % R;
+        tk[ps] = (b * R + y) * R + x;
+        rgs[ps] = p.shift > 0 ? swin_region(ys, R, w, p.shift) * 3 + swin_region(xs, R, w, p.shift) : 0;
+        kc[ps] = *reinterpret_cast<const bf16x8*>(qkv + (long)tk[ps] * ld + C + h * HD + sub * 8);
+        vc[ps] = *reinterpret_cast<const bf16x8*>(qkv + (long)tk[ps] * ld + 2 * C + h * HD + sub * 8);
+      }
+    }
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int j = ps * 16 + r4;
       float ss = 0.f;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        kc[c] = *reinterpret_cast<const bf16x8*>(kr + c * 8);
-        vc[c] = *reinterpret_cast<const bf16x8*>(vr + c * 8);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const float f = (float)kc[c][u]; ss += f * f; }
-      }
+      for (int u = 0; u < 8; ++u) { const float f = (float)kc[ps][u]; ss += f * f; }
+      ss += __shfl_xor(ss, 1, 64);
+      ss += __shfl_xor(ss, 2, 64);
       const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int u = 0; u < 8; ++u) kc[c][u] = (bf16_t)((float)kc[c][u] * inv);
-    }
-    tok[j] = t; reg[j] = rg;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      *reinterpret_cast<bf16x8*>(Kr + j * KP + c * 16) = kc[c];
-      *reinterpret_cast<bf16x8*>(Vt + swin_tr_off(j, c * 8)) = vc[c];
+      for (int u = 0; u < 8; ++u) kc[ps][u] = (bf16_t)((float)kc[ps][u] * inv);
+      if (sub == 0) { tok[j] = tk[ps]; reg[j] = rgs[ps]; }
+      *reinterpret_cast<bf16x8*>(Kr + j * KP + sub * 16) = kc[ps];
+      *reinterpret_cast<bf16x8*>(Vt + swin_tr_off(j, sub * 8)) = vc[ps];
     }
   }
   __syncthreads();
   const float scale = __expf(fminf(p.logit_scale[h], 4.6051701859880914f));
   bf16_t* ctx = reinterpret_cast<bf16_t*>(p.ctx);
   const int nqt = (n + 15) / 16;
+  // Q fragment and the query's 64 bias values are fetched one q-tile ahead (they were a global round trip per tile)
+  auto fetch = [&](int qt, bf16x8& qv, f32x4 (&bv)[4]) {
+    const int q = qt * 16 + (lane & 15);
+    const int qc = q < n ? q : n - 1;
+    qv = *reinterpret_cast<const bf16x8*>(qkv + (long)tok[qc] * ld + h * HD + g * 8);
+    const float* brow = p.bias + ((long)h * n + qc) * n;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int key = t * 16 + g * 4 + r; bv[t][r] = brow[key < n ? key : n - 1]; }
+  };
+  bf16x8 qnext; f32x4 bnext[4];
+  fetch(0, qnext, bnext);
   for (int qt = 0; qt < nqt; ++qt) {
     const int q = qt * 16 + (lane & 15);
     const int qc = q < n ? q : n - 1;
     const int tq = tok[qc], rq = reg[qc];
+    bf16x8 qv = qnext;
+    f32x4 bcur[4] = {bnext[0], bnext[1], bnext[2], bnext[3]};
+    if (qt + 1 < nqt) fetch(qt + 1, qnext, bnext);
     // Q-hat fragment: 8 of the row's 32 values per lane; the row norm is completed across the 4 lane groups
-    bf16x8 qv = *reinterpret_cast<const bf16x8*>(qkv + (long)tq * ld + h * HD + g * 8);
     float ss = 0.f;
 #pragma unroll
     for (int u = 0; u < 8; ++u) { const float f = (float)qv[u]; ss += f * f; }
@@ -212,7 +230,6 @@ __global__ __launch_bounds__(64) void swin_attn_fwd_mfma32(SwinAttnP p) {
     for (int u = 0; u < 8; ++u) qv[u] = (bf16_t)((float)qv[u] * qs);
     f32x4 st[4];
     float m = -INFINITY;
-    const float* brow = p.bias + ((long)h * n + qc) * n;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kr + (t * 16 + (lane & 15)) * KP + g * 16);
@@ -222,7 +239,7 @@ __global__ __launch_bounds__(64) void swin_attn_fwd_mfma32(SwinAttnP p) {
         const int key = t * 16 + g * 4 + r;
         float x = -INFINITY;
         if (key < n) {
-          x = st[t][r] * scale + brow[key];
+          x = st[t][r] * scale + bcur[t][r];
           if (reg[key] != rq) x += -200.f;  // -100 twice (HF/swinv2:433-436)
         }
         st[t][r] = x;
