@@ -207,20 +207,25 @@ __global__ __launch_bounds__(256) void t5_attn_bwd_mfma(AttnMP p) {
   const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
 
+  bool staged_delta = false;  // the fast staging path below also produces delta / lse (no second round of loads)
   {
     // all global loads of the four operand slices go out before the first LDS store (one memory round trip instead of
     // one per chunk: the per-matrix loops were 8-12 dependent load -> store pairs)
     constexpr int CPR = DKP / 8, MAXC = 4;
     const int nq = Lqp * CPR, nk = Lkp * CPR;
     if (nq <= MAXC * 256 && nk <= MAXC * 256) {
-      bf16x8 vq[MAXC], vk[MAXC], vv[MAXC], vd[MAXC];
+      bf16x8 vq[MAXC], vk[MAXC], vv[MAXC], vd[MAXC], vo[MAXC];
+      float lsev[MAXC];
 #pragma unroll
       for (int i = 0; i < MAXC; ++i) {
         const int ch = threadIdx.x + i * 256, r = ch / CPR, c = (ch % CPR) * 8;
-        vq[i] = bf16x8{}; vk[i] = bf16x8{}; vv[i] = bf16x8{}; vd[i] = bf16x8{};
+        vq[i] = bf16x8{}; vk[i] = bf16x8{}; vv[i] = bf16x8{}; vd[i] = bf16x8{}; vo[i] = bf16x8{};
+        lsev[i] = INFINITY;  // padded queries: P = exp(-inf) = 0
         if (ch < nq && r < Lq && c < DK) {
           vq[i] = *reinterpret_cast<const bf16x8*>(p.q + ((long)b * Lq + r) * p.ldq + (long)h * DK + c);
           vd[i] = *reinterpret_cast<const bf16x8*>(p.dctx + ((long)b * Lq + r) * p.lddo + (long)h * DK + c);
+          if constexpr (DK % 8 == 0) vo[i] = *reinterpret_cast<const bf16x8*>(p.ctx + ((long)b * Lq + r) * p.ldo + (long)h * DK + c);
+          if (c == 0) lsev[i] = p.lse[((long)b * p.H + h) * Lq + r];
         }
         if (ch < nk && r < Lk && c < DK) {
           vk[i] = *reinterpret_cast<const bf16x8*>(p.k + ((long)b * Lk + r) * p.ldk + (long)h * DK + c);
@@ -244,7 +249,15 @@ __global__ __launch_bounds__(256) void t5_attn_bwd_mfma(AttnMP p) {
           *reinterpret_cast<bf16x8*>(Vr + r * KPITCH + c * 2) = vv[i];
           if (tr) *reinterpret_cast<bf16x8*>(Kt + TrImg<DKP>::off(r, c)) = vk[i];
         }
+        // delta[q] = dO[q,:] . O[q,:] from the chunks already in registers: the CPR lanes of a row are neighbours
+        float a = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += (float)vd[i][u] * (float)vo[i][u];
+#pragma unroll
+        for (int o2 = 1; o2 < CPR; o2 <<= 1) a += __shfl_xor(a, o2, 64);
+        if (ch < nq && c == 0) { delta[r] = a; lses[r] = lsev[i]; }
       }
+      staged_delta = true;
     } else {
       stage<DK, DKP, true, true>(p.q, p.ldq, b, h, Lq, Lqp, Qr, KPITCH, Qt);
       stage<DK, DKP, true, true>(p.k, p.ldk, b, h, Lk, Lkp, Kr, KPITCH, Kt);
@@ -254,7 +267,7 @@ __global__ __launch_bounds__(256) void t5_attn_bwd_mfma(AttnMP p) {
   }
   // delta[q] = dO[q,:] . O[q,:] and the row's log-sum-exp: 4 lanes per row with 8-byte loads, all rows of the block in
   // flight at once (one row per wave at a time made this ~20 dependent global round trips, most of the kernel's time)
-  for (int r0 = 0; r0 < Lqp; r0 += 64) {
+  for (int r0 = 0; r0 < (staged_delta ? 0 : Lqp); r0 += 64) {
     constexpr int EPS = DK / 4;
     const int qq = r0 + (threadIdx.x >> 2), seg = threadIdx.x & 3;
     float a = 0.f;
@@ -496,7 +509,7 @@ int t5_attn_fwd_mfma_dispatch(const klab_attn_args* a, hipStream_t s) {
   return KLAB_ERR_UNSUPPORTED;
 }
 int t5_attn_bwd_mfma_dispatch(const klab_attn_args* a, hipStream_t s) {
-  if (a->dtype != KLAB_BF16 || (a->ldo & 3) || (a->ldq & 7) || (a->ldk & 7) || (a->ldv & 7) || (a->lddo & 7) || (a->lddq & 3) ||
+  if (a->dtype != KLAB_BF16 || (a->ldo & 7) || (a->ldq & 7) || (a->ldk & 7) || (a->ldv & 7) || (a->lddo & 7) || (a->lddq & 3) ||
       (a->lddk & 3) || (a->lddv & 3))
     return KLAB_ERR_UNSUPPORTED;
   AttnMP p = to_mp(a);
