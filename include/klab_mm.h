@@ -80,6 +80,14 @@ int klab_rmsnorm_bwd(const float* dy, const float* x, const float* w, const floa
                      void* dxt, int dxt_dtype, float* dw, int rows, int d, int grp, int grp_stride, int off,
                      float p_y, uint32_t tag_y, float p_prev, uint32_t tag_prev, const uint32_t* seed_dev,
                      void* stream);
+/* Deferred weight gradient: same as klab_rmsnorm_bwd, but dw is left as per-workgroup partial sums
+ * dw_part[klab_rmsnorm_part_rows(rows), d]; several calls' partials (call c at part + c*call_stride) are then folded into
+ * their dw vectors by ONE klab_colpart_reduce (fixed summation order: bit-reproducible, and no same-address atomics). */
+int klab_rmsnorm_part_rows(int rows);
+int klab_rmsnorm_bwd_part(const float* dy, const float* x, const float* w, const float* rstd, const float* dres, float* dx, void* dxt,
+                          int dxt_dtype, float* dw_part, int rows, int d, int grp, int grp_stride, int off, float p_y, uint32_t tag_y,
+                          float p_prev, uint32_t tag_prev, const uint32_t* seed_dev, void* stream);
+int klab_colpart_reduce(const float* part, long call_stride, int nparts, int d, float* const* dst_dev, int ncalls, void* stream);
 
 /* ---- Swin-V2 LayerNorm, res-post-norm form (HF/swinv2:697-702; also :242, :354, :953) --------
  * out = drop(shortcut + LN(y)*gamma + beta)  (f32, remapped rows) and/or outt (dtype copy).     */

@@ -98,6 +98,8 @@ struct klab_engine {
   float* G[3] = {nullptr, nullptr, nullptr};
   void* warena = nullptr; float* farena = nullptr;
   void* cast_desc = nullptr; int n_cast = 0; long cast_total4 = 0;      // trainable GEMM weights (cast every forward)
+  // RMS-norm weight gradients of a stack: per-workgroup partials of every norm, folded by one reduction per stack
+  float* rms_part = nullptr; long rms_part_stride = 0; float** rms_dst_dev[2] = {nullptr, nullptr}; int rms_ncalls[2] = {0, 0};
   void* cast_desc_frozen = nullptr; int n_cast_frozen = 0; long cast_total4_frozen = 0;  // frozen towers (cast when dirty)
   bool frozen_valid = false;  // arena copies + CPB bias tables of the frozen towers are up to date
   void* fcast_desc = nullptr; int n_fcast = 0; long fcast_total4 = 0;
@@ -391,6 +393,15 @@ size_t plan_workspace(klab_engine* e, void* base, int B, int Ls, int Lt) {
   e->farena = (float*)b.take((size_t)e->farena_elems * 4);
   e->cast_desc = b.take(sizeof(long) * 3 * 2 * (e->P[0].size() + e->P[1].size() + e->P[2].size() + 1));  // two groups
   e->fcast_desc = b.take(sizeof(long) * 3 * (e->P[0].size() + 1));
+  {
+    const int nle = c.main.n_layers, nldx = c.main.n_dec_layers;
+    const int ncmax = (2 * nle + 1) > (3 * nldx + 1) ? (2 * nle + 1) : (3 * nldx + 1);
+    const long Mmax = (long)B * (Le > Lt ? Le : Lt);
+    e->rms_part_stride = (long)klab_rmsnorm_part_rows((int)Mmax) * c.main.d_model;
+    e->rms_part = (float*)b.take((size_t)ncmax * e->rms_part_stride * 4);
+    e->rms_dst_dev[0] = (float**)b.take(sizeof(float*) * (2 * nle + 1));
+    e->rms_dst_dev[1] = (float**)b.take(sizeof(float*) * (3 * nldx + 1));
+  }
 
   plan_t5_stack(b, c.lang, c.lang.n_layers, false, false, B * Ls, B, Ls, es, e->lang, 0);
   plan_t5_stack(b, c.main, c.main.n_layers, false, true, (int)Me, B, Le, es, e->enc, 0);
@@ -639,12 +650,24 @@ int t5_stack_backward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Pa
   const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
   int dy_i = 0, deferred = 0;
   WgradQueue wq;
+  // norm-weight gradients: per-workgroup partials now, ONE fixed-order reduction for the whole stack at the end (the
+  // 256-way same-address f32 atomics cost ~3 us in each of the stack's 13-19 norm backward kernels)
+  const int stk = dec ? 1 : 0;
+  const bool part_ok = Gflat == e->G[2] && e->rms_part && d <= 1024 && (long)klab_rmsnorm_part_rows(M) * d <= e->rms_part_stride;
+  int rms_calls = 0;
+  auto rms_bwd = [&](const float* dyin, const float* x, const float* w, const float* rstd, const float* dres, float* dx, void* dxt, int pidx,
+                     float p_y, uint32_t tag_y, float p_prev, uint32_t tag_prev) -> int {
+    if (part_ok)
+      return klab_rmsnorm_bwd_part(dyin, x, w, rstd, dres, dx, dxt, c.dt, e->rms_part + (long)(rms_calls++) * e->rms_part_stride, M, d, 0, 0, 0,
+                                   p_y, tag_y, p_prev, tag_prev, e->seed_dev, c.ws());
+    return klab_rmsnorm_bwd(dyin, x, w, rstd, dres, dx, dxt, c.dt, G(pidx), M, d, 0, 0, 0, p_y, tag_y, p_prev, tag_prev, e->seed_dev, c.ws());
+  };
   auto next_dy = [&]() { return e->dy_pool[dy_i++ % e->dy_pool.size()]; };
   RC(hipMemsetAsync(s.dbias, 0, (size_t)H * Lq * Lq * 4, c.s));
   // final norm: y = drop(norm(h[j])); previous sub-layer output dropout = FFN_OUT of the last layer
   void* dy = next_dy();  // masked, compute-dtype gradient of the current sub-layer's GEMM output
-  RC(klab_rmsnorm_bwd(e->dxn, s.h[j], W[final_ln], s.rstd_f, nullptr, dh_cur, dy, c.dt, G(final_ln), M, d, 0, 0, 0, p,
-                      tag_of(stack_id, 0, SITE_FINAL), p, tag_of(stack_id, (int)L.size() - 1, SITE_FFN_OUT), e->seed_dev, c.ws()));
+  RC(rms_bwd(e->dxn, s.h[j], W[final_ln], s.rstd_f, nullptr, dh_cur, dy, final_ln, p, tag_of(stack_id, 0, SITE_FINAL), p,
+             tag_of(stack_id, (int)L.size() - 1, SITE_FFN_OUT)));
   for (int i = (int)L.size() - 1; i >= 0; --i) {
     const T5LayerIdx& l = L[i];
     T5LayerBufs& b = s.L[i];
@@ -663,8 +686,7 @@ int t5_stack_backward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Pa
     {
       const uint32_t tprev = dec ? tag_of(stack_id, i, SITE_XOUT) : tag_of(stack_id, i, SITE_ATTN_OUT);
       dy = next_dy();
-      RC(klab_rmsnorm_bwd(e->dxn, s.h[j], W[l.ln2], b.rstd3, dh_cur, dh_oth, dy, c.dt, G(l.ln2), M, d, 0, 0, 0, 0.f, 0, p, tprev,
-                          e->seed_dev, c.ws()));
+      RC(rms_bwd(e->dxn, s.h[j], W[l.ln2], b.rstd3, dh_cur, dh_oth, dy, l.ln2, 0.f, 0, p, tprev));
       float* t = dh_cur; dh_cur = dh_oth; dh_oth = t;
     }
     if (dec) {  // ---------------- cross attention ----------------
@@ -686,8 +708,7 @@ int t5_stack_backward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Pa
       wq.push(dqc, inner, b.xn2, d, M, inner, d, G(l.cq));
       RC(linear_dgrad(c, dqc, inner, M, inner, P[l.cq].warena_off, d, e->dxn, KLAB_F32));
       dy = next_dy();
-      RC(klab_rmsnorm_bwd(e->dxn, s.h[j], W[l.ln1], b.rstd2, dh_cur, dh_oth, dy, c.dt, G(l.ln1), M, d, 0, 0, 0, 0.f, 0, p,
-                          tag_of(stack_id, i, SITE_ATTN_OUT), e->seed_dev, c.ws()));
+      RC(rms_bwd(e->dxn, s.h[j], W[l.ln1], b.rstd2, dh_cur, dh_oth, dy, l.ln1, 0.f, 0, p, tag_of(stack_id, i, SITE_ATTN_OUT)));
       float* t = dh_cur; dh_cur = dh_oth; dh_oth = t;
     }
     // ---------------- self attention ----------------
@@ -719,11 +740,15 @@ int t5_stack_backward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Pa
     {
       const bool first = (i == 0);
       if (!first) dy = next_dy();
-      RC(klab_rmsnorm_bwd(e->dxn, s.h[j], W[l.ln0], b.rstd1, dh_cur, dh_oth, first ? nullptr : dy, c.dt, G(l.ln0), M, d, 0, 0, 0, 0.f, 0,
-                          first ? 0.f : p, first ? 0u : tag_of(stack_id, i - 1, SITE_FFN_OUT), e->seed_dev, c.ws()));
+      RC(rms_bwd(e->dxn, s.h[j], W[l.ln0], b.rstd1, dh_cur, dh_oth, first ? nullptr : dy, l.ln0, 0.f, 0, first ? 0.f : p,
+                 first ? 0u : tag_of(stack_id, i - 1, SITE_FFN_OUT)));
       float* t = dh_cur; dh_cur = dh_oth; dh_oth = t;
     }
     RC(wq.flush(c));  // this layer's weight gradients: one event, then they overlap the next layer's chain
+  }
+  if (part_ok && rms_calls) {
+    if (rms_calls != e->rms_ncalls[stk]) return KLAB_ERR_BADARG;  // the destination table was built for exactly this visiting order
+    RC(klab_colpart_reduce(e->rms_part, e->rms_part_stride, klab_rmsnorm_part_rows(M), d, e->rms_dst_dev[stk], rms_calls, c.ws()));
   }
   if (deferred) RC(klab_dbias_reduce(e->ds_ws, c.dt, s.dbias, deferred * B, H, Lq, Lq, c.ws()));
   RC(klab_relbias_bwd(s.dbias, s.bucket, G(L[0].relb), H, Lq, Lq, cfg.rel_buckets, c.ws()));
@@ -958,6 +983,23 @@ extern "C" int klab_engine_bind(klab_engine* e, int B, int Ls, int Lt, void* wor
       er = hipStreamSynchronize(hs);
       if (er != hipSuccess) return (int)er;
     }
+  }
+  for (int st = 0; st < 2; ++st) {  // norm-weight gradient destinations in the order the stack's backward visits them
+    const bool dec = st == 1;
+    const auto& L = dec ? e->mi.dec : e->mi.enc;
+    std::vector<float*> dst;
+    float* Gm = e->G[2];
+    dst.push_back(Gm + e->P[2][dec ? e->mi.dec_final : e->mi.enc_final].grad_off);
+    for (int i = (int)L.size() - 1; i >= 0; --i) {
+      dst.push_back(Gm + e->P[2][L[i].ln2].grad_off);
+      if (dec) dst.push_back(Gm + e->P[2][L[i].ln1].grad_off);
+      dst.push_back(Gm + e->P[2][L[i].ln0].grad_off);
+    }
+    e->rms_ncalls[st] = (int)dst.size();
+    hipError_t er = hipMemcpyAsync(e->rms_dst_dev[st], dst.data(), dst.size() * sizeof(float*), hipMemcpyHostToDevice, hs);
+    if (er != hipSuccess) return (int)er;
+    er = hipStreamSynchronize(hs);
+    if (er != hipSuccess) return (int)er;
   }
   RC((int)hipMemsetAsync(e->seed_dev, 0, 512, hs));
   for (auto& g : e->gs) {

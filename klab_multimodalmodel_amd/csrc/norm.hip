@@ -132,7 +132,7 @@ __global__ __launch_bounds__(1024) void rmsnorm_bwd_dw_kernel(const float* __res
                                                              const float* __restrict__ dres, float* __restrict__ dx,
                                                              TY* __restrict__ dxt, float* __restrict__ dw, int rows, int d,
                                                              int grp, int grp_stride, int off, float p_y, uint32_t tag_y,
-                                                             float p_prev, uint32_t tag_prev, const uint32_t* seed) {
+                                                             float p_prev, uint32_t tag_prev, const uint32_t* seed, int partial) {
   constexpr int WPB = 16;  // 16 waves per workgroup: one row per wave in flight (the kernel is latency-bound), and the
                            // weight-gradient partials of 16+ rows fold into ONE atomic per column
   __shared__ float red[WPB][256 * SLOTS];
@@ -200,7 +200,8 @@ __global__ __launch_bounds__(1024) void rmsnorm_bwd_dw_kernel(const float* __res
     float a = 0.f;
 #pragma unroll
     for (int w = 0; w < WPB; ++w) a += red[w][c];
-    atomicAdd(dw + c, a);
+    if (partial) dw[(long)blockIdx.x * d + c] = a;  // dw = per-workgroup partials [gridDim.x, d]: reduced once per stack, in a fixed order
+    else atomicAdd(dw + c, a);
   }
 }
 
@@ -384,6 +385,56 @@ extern "C" int klab_rmsnorm_fwd(const float* x, const float* w, void* y, int y_d
   return KLAB_OK;
 }
 
+static int rms_part_rows(int rows) {
+  static const int nblk = [] { const char* v = getenv("KLAB_RMS_BLOCKS"); int n = v ? atoi(v) : 512; return n < 1 ? 1 : n; }();
+  const int g16 = (rows + 15) / 16;
+  return g16 < nblk ? g16 : nblk;
+}
+static int rms_fused_launch(const float* dy, const float* x, const float* w, const float* rstd, const float* dres, float* dx, void* dxt,
+                            int dxt_dtype, float* dw, int partial, int rows, int d, int grp, int grp_stride, int off, float p_y,
+                            uint32_t tag_y, float p_prev, uint32_t tag_prev, const uint32_t* seed_dev, hipStream_t s) {
+  const int gf = rms_part_rows(rows);
+#define RB_LAUNCH(TY, SL)                                                                                                      \
+  hipLaunchKernelGGL((rmsnorm_bwd_dw_kernel<TY, SL>), dim3(gf), dim3(1024), 0, s, dy, x, w, rstd, dres, dx, (TY*)dxt, dw, rows, d, grp, \
+                     grp_stride, off, p_y, tag_y, p_prev, tag_prev, seed_dev, partial)
+  if (dxt_dtype == KLAB_BF16) { if (d <= 256) RB_LAUNCH(bf16_t, 1); else if (d <= 512) RB_LAUNCH(bf16_t, 2); else RB_LAUNCH(bf16_t, 4); }
+  else { if (d <= 256) RB_LAUNCH(float, 1); else if (d <= 512) RB_LAUNCH(float, 2); else RB_LAUNCH(float, 4); }
+#undef RB_LAUNCH
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+
+extern "C" int klab_rmsnorm_part_rows(int rows) { return rows > 0 ? rms_part_rows(rows) : 0; }
+
+// as klab_rmsnorm_bwd, but the weight gradient is left as per-workgroup partial sums dw_part[klab_rmsnorm_part_rows(rows), d]
+extern "C" int klab_rmsnorm_bwd_part(const float* dy, const float* x, const float* w, const float* rstd, const float* dres, float* dx,
+                                     void* dxt, int dxt_dtype, float* dw_part, int rows, int d, int grp, int grp_stride, int off, float p_y,
+                                     uint32_t tag_y, float p_prev, uint32_t tag_prev, const uint32_t* seed_dev, void* stream) {
+  if (!dy || !x || !w || !rstd || !dw_part || rows <= 0 || d <= 0 || (d & 3)) return KLAB_ERR_BADARG;
+  if (d > 1024) return KLAB_ERR_UNSUPPORTED;
+  return rms_fused_launch(dy, x, w, rstd, dres, dx, dxt, dxt_dtype, dw_part, 1, rows, d, grp, grp_stride, off, p_y, tag_y, p_prev, tag_prev,
+                          seed_dev, (hipStream_t)stream);
+}
+
+// dst[c][col] += sum_b part[c * call_stride + b * d + col]   (b < nparts), one thread per (call, column), fixed order
+__global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __restrict__ part, long call_stride, int nparts, int d,
+                                                             float* const* __restrict__ dst) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= d) return;
+  const float* src = part + (long)blockIdx.y * call_stride + col;
+  float a = 0.f;
+#pragma unroll 8
+  for (int b = 0; b < nparts; ++b) a += src[(long)b * d];
+  dst[blockIdx.y][col] += a;
+}
+extern "C" int klab_colpart_reduce(const float* part, long call_stride, int nparts, int d, float* const* dst_dev, int ncalls, void* stream) {
+  if (!part || !dst_dev || nparts <= 0 || d <= 0 || ncalls <= 0) return KLAB_ERR_BADARG;
+  hipLaunchKernelGGL(colpart_reduce_kernel, dim3((d + 255) / 256, ncalls), dim3(256), 0, (hipStream_t)stream, part, call_stride, nparts, d,
+                     dst_dev);
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+
 extern "C" int klab_rmsnorm_bwd(const float* dy, const float* x, const float* w, const float* rstd, const float* dres,
                                 float* dx, void* dxt, int dxt_dtype, float* dw, int rows, int d, int grp, int grp_stride,
                                 int off, float p_y, uint32_t tag_y, float p_prev, uint32_t tag_prev,
@@ -392,19 +443,8 @@ extern "C" int klab_rmsnorm_bwd(const float* dy, const float* x, const float* w,
   if (rows == 0) return KLAB_OK;
   hipStream_t s = (hipStream_t)stream;
   const int g = norm_grid(rows);
-  if (dw && d <= 1024) {  // fused row + dw kernel
-    static const int nblk = [] { const char* v = getenv("KLAB_RMS_BLOCKS"); int n = v ? atoi(v) : 512; return n < 1 ? 1 : n; }();
-    const int g16 = (rows + 15) / 16;
-    const int gf = g16 < nblk ? g16 : nblk;
-#define RB_LAUNCH(TY, SL)                                                                                                      \
-  hipLaunchKernelGGL((rmsnorm_bwd_dw_kernel<TY, SL>), dim3(gf), dim3(1024), 0, s, dy, x, w, rstd, dres, dx, (TY*)dxt, dw, rows, d, grp, \
-                     grp_stride, off, p_y, tag_y, p_prev, tag_prev, seed_dev)
-    if (dxt_dtype == KLAB_BF16) { if (d <= 256) RB_LAUNCH(bf16_t, 1); else if (d <= 512) RB_LAUNCH(bf16_t, 2); else RB_LAUNCH(bf16_t, 4); }
-    else { if (d <= 256) RB_LAUNCH(float, 1); else if (d <= 512) RB_LAUNCH(float, 2); else RB_LAUNCH(float, 4); }
-#undef RB_LAUNCH
-    KLAB_LAUNCH_CHECK();
-    return KLAB_OK;
-  }
+  if (dw && d <= 1024)  // fused row + dw kernel
+    return rms_fused_launch(dy, x, w, rstd, dres, dx, dxt, dxt_dtype, dw, 0, rows, d, grp, grp_stride, off, p_y, tag_y, p_prev, tag_prev, seed_dev, s);
   if (dxt_dtype == KLAB_BF16)
     hipLaunchKernelGGL(rmsnorm_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, s, dy, x, w, rstd, dres, dx, (bf16_t*)dxt, rows,
                        d, grp, grp_stride, off, p_y, tag_y, p_prev, tag_prev, seed_dev);
