@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE configs[1]: 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--optimizer", choices=["klab", "torch"], default="klab",
+                    help="klab: klab_multimodalmodel_amd.optim.FusedAdam (same update rule as torch.optim.Adam, one kernel); torch: torch.optim.Adam(fused=True)")
     ap.add_argument("--graph", action="store_true", help="replay the engine's launch sequences as hipGraphs (measured: no gain "
                     "while the step is GPU-bound; kept for when it becomes launch-bound)")
     a = ap.parse_args()
@@ -133,7 +135,11 @@ def main():
         core = model
         core._direct_grads = True  # grads land in the flat buffer (no autograd copies); same math
     core.use_graph = bool(a.graph)  # forward / backward launch sequences replayed as hipGraphs (same kernels, same math)
-    optimizer = torch.optim.Adam(core.transformer.parameters(), lr=1e-3, fused=True)  # ref/train.py:28 (same optimizer class, fused multi-tensor kernel)
+    if a.optimizer == "klab":  # torch.optim.Adam's update rule in one kernel over the flat buffers (+ bf16 weight copies)
+        from klab_multimodalmodel_amd.optim import FusedAdam
+        optimizer = FusedAdam(core.transformer.parameters(), lr=1e-3)
+    else:                      # ref/train.py:28 verbatim (torch's own fused multi-tensor kernel)
+        optimizer = torch.optim.Adam(core.transformer.parameters(), lr=1e-3, fused=True)
     core.transformer.train()                                               # ref/train.py:52
 
     B, Ls, Lt = a.batch, 9, 64
@@ -180,7 +186,9 @@ def main():
             "config": {"workload": "BASELINE configs[1]: Swin-V2(C=64,(2,2,6,2),224,w7) frozen + T5-small, fwd+bwd+Adam, "
                                    "T5 dropout 0.1 on, random-init weights",
                        "global_batch": world * B, "per_gpu_batch": B, "src_len": Ls, "tgt_len": Lt,
-                       "parallelism": f"dp{world}", "hipgraph": bool(core.use_graph), "fwd_bwd_gflop_per_sample": GFLOP_PER_SAMPLE["cfg2"],
+                       "parallelism": f"dp{world}", "hipgraph": bool(core.use_graph),
+                       "optimizer": ("klab.optim.FusedAdam (Adam update of ref/train.py:28, one kernel)" if a.optimizer == "klab"
+                                     else "torch.optim.Adam(fused=True)"), "fwd_bwd_gflop_per_sample": GFLOP_PER_SAMPLE["cfg2"],
                        "step_mfma_frac": round(B * GFLOP_PER_SAMPLE["cfg2"] / (ms * 1e-3) / 1e3 / PEAK_BF16_TFLOPS, 4),
                        "host_enqueue_ms_per_step": round(host_ms, 3), "final_loss": round(lossv, 4)},
         }

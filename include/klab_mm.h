@@ -240,6 +240,15 @@ int klab_engine_forward(klab_engine* e, const float* pixels, const long long* sr
 /* hipGraph replay of the forward / backward launch sequences (first use eager, second captured, then replayed;
  * inputs are staged into engine-owned buffers so node addresses stay fixed).  Off by default.          */
 int klab_engine_set_graph(klab_engine* e, int on);
+/* torch.optim.Adam's update (ref/train.py:28; no amsgrad, L2 weight decay) for ALL parameters of the
+ * trainable T5 in one pass.  m / v: caller-owned f32 state laid out like the "main" flat gradient buffer.  bias_corr{1,2} =
+ * 1 - beta^step.  Also refreshes the compute-dtype copies of the GEMM weights, so the next klab_engine_forward may be
+ * told (training bit 2) that they are current. */
+int klab_engine_adam_step(klab_engine* e, float* m, float* v, float lr, float beta1, float beta2, float eps, float weight_decay,
+                          float bias_corr1, float bias_corr2, void* stream);
+/* the kernel behind it: desc = device array of {float* p; long grad_off; long arena_off (<0: none); long n4_prefix} */
+int klab_adam_step(const void* desc_dev, int ndesc, long total4, const float* grads, float* m, float* v, void* arena, int dtype, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, void* stream);
 /* segment 0: LM head + decoder + tied embedding; 1: encoder; 2: Swin (no-op unless train_swin).
  * dloss_dev: device scalar d(objective)/d(loss) (NULL = 1).                                       */
 int klab_engine_backward(klab_engine* e, int segment, const float* dloss_dev, void* stream);

@@ -98,6 +98,7 @@ struct klab_engine {
   float* G[3] = {nullptr, nullptr, nullptr};
   void* warena = nullptr; float* farena = nullptr;
   void* cast_desc = nullptr; int n_cast = 0; long cast_total4 = 0;      // trainable GEMM weights (cast every forward)
+  void* adam_desc = nullptr; int n_adam = 0; long adam_total4 = 0;        // fused optimizer step over the trainable T5 (f-2)
   // RMS-norm weight gradients of a stack: per-workgroup partials of every norm, folded by one reduction per stack
   float* rms_part = nullptr; long rms_part_stride = 0; float** rms_dst_dev[2] = {nullptr, nullptr}; int rms_ncalls[2] = {0, 0};
   void* cast_desc_frozen = nullptr; int n_cast_frozen = 0; long cast_total4_frozen = 0;  // frozen towers (cast when dirty)
@@ -393,6 +394,7 @@ size_t plan_workspace(klab_engine* e, void* base, int B, int Ls, int Lt) {
   e->farena = (float*)b.take((size_t)e->farena_elems * 4);
   e->cast_desc = b.take(sizeof(long) * 3 * 2 * (e->P[0].size() + e->P[1].size() + e->P[2].size() + 1));  // two groups
   e->fcast_desc = b.take(sizeof(long) * 3 * (e->P[0].size() + 1));
+  e->adam_desc = b.take(sizeof(long) * 4 * (e->P[2].size() + 1));
   {
     const int nle = c.main.n_layers, nldx = c.main.n_dec_layers;
     const int ncmax = (2 * nle + 1) > (3 * nldx + 1) ? (2 * nle + 1) : (3 * nldx + 1);
@@ -984,6 +986,25 @@ extern "C" int klab_engine_bind(klab_engine* e, int B, int Ls, int Lt, void* wor
       if (er != hipSuccess) return (int)er;
     }
   }
+  {  // fused Adam descriptors: every trainable tensor of the main T5 (tied tables appear once)
+    std::vector<long> d;
+    long pre = 0; int n = 0;
+    bool ok = true;
+    for (size_t i = 0; i < e->P[2].size(); ++i) {
+      const ParamInfo& p = e->P[2][i];
+      if (p.grad_off < 0) continue;
+      if (p.numel % 4 || (p.grad_off & 3) || (p.warena_off >= 0 && (p.warena_off & 3))) { ok = false; break; }
+      d.push_back((long)e->W[2][i]); d.push_back(p.grad_off); d.push_back(p.warena_off); d.push_back(pre);
+      pre += p.numel / 4; ++n;
+    }
+    e->n_adam = ok ? n : 0; e->adam_total4 = pre;
+    if (e->n_adam) {
+      hipError_t er = hipMemcpyAsync(e->adam_desc, d.data(), d.size() * sizeof(long), hipMemcpyHostToDevice, hs);
+      if (er != hipSuccess) return (int)er;
+      er = hipStreamSynchronize(hs);
+      if (er != hipSuccess) return (int)er;
+    }
+  }
   for (int st = 0; st < 2; ++st) {  // norm-weight gradient destinations in the order the stack's backward visits them
     const bool dec = st == 1;
     const auto& L = dec ? e->mi.dec : e->mi.enc;
@@ -1070,14 +1091,14 @@ int run_graphed(klab_engine* e, int slot, hipStream_t s, F body) {
 }
 
 // everything of the forward before the LM head (inputs are the engine-owned staged copies)
-int forward_part_a(klab_engine* e, hipStream_t stream, float p, bool refresh_frozen) {
+int forward_part_a(klab_engine* e, hipStream_t stream, float p, bool refresh_frozen, bool trainable_current) {
   Ctx c{e, stream, e->cfg.dtype, e->es};
   const klab_model_cfg& cfg = e->cfg;
   const float* pixels = e->pixels_buf;
   const long long *src_ids = e->src_buf, *tgt_ids = e->tgt_buf;
   hipLaunchKernelGGL(seed_step_kernel, dim3(1), dim3(1), 0, c.s, e->seed_dev);
   // 1. weights: fp32 masters -> compute-dtype arena (+ fused f32 bias vectors)
-  if (e->n_cast) RC(klab_cast_pack(e->cast_desc, e->n_cast, e->cast_total4, e->warena, c.dt, c.ws()));
+  if (e->n_cast && !trainable_current) RC(klab_cast_pack(e->cast_desc, e->n_cast, e->cast_total4, e->warena, c.dt, c.ws()));
   if (refresh_frozen || e->cfg.train_swin) {
     if (refresh_frozen && e->n_cast_frozen)
       RC(klab_cast_pack(e->cast_desc_frozen, e->n_cast_frozen, e->cast_total4_frozen, e->warena, c.dt, c.ws()));
@@ -1115,6 +1136,14 @@ int forward_part_a(klab_engine* e, hipStream_t stream, float p, bool refresh_fro
 
 }  // namespace
 
+extern "C" int klab_engine_adam_step(klab_engine* e, float* m, float* v, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                     float bias_corr1, float bias_corr2, void* stream) {
+  if (!e || !e->bound || !m || !v || !e->G[2]) return KLAB_ERR_BADARG;
+  if (!e->n_adam) return KLAB_ERR_UNSUPPORTED;
+  return klab_adam_step(e->adam_desc, e->n_adam, e->adam_total4, e->G[2], m, v, e->warena, e->cfg.dtype, lr, beta1, beta2, eps, weight_decay,
+                        bias_corr1, bias_corr2, stream);
+}
+
 extern "C" int klab_engine_set_graph(klab_engine* e, int on) {
   if (!e) return KLAB_ERR_BADARG;
   e->use_graph = on != 0;
@@ -1145,11 +1174,14 @@ extern "C" int klab_engine_forward(klab_engine* e, const float* pixels, const lo
     hipLaunchKernelGGL(seed_set_kernel, dim3(1), dim3(1), 0, c.s, e->seed_dev, seed);
     e->seed_base = seed; e->seed_set = true;
   }
+  // bit 2: the optimizer step (klab_engine_adam_step) already refreshed the trainable weights' compute-dtype copies.
+  // Ignored under graph replay, whose captured sequence always contains the cast.
+  const bool tcur = (training & 4) && !e->use_graph;
   if (refresh_frozen) {  // not worth a graph slot: happens once per weight version
-    RC(forward_part_a(e, c.s, p, true));
+    RC(forward_part_a(e, c.s, p, true, tcur));
     e->frozen_valid = true;
   } else {
-    RC(run_graphed(e, (training & 1) ? 1 : 0, c.s, [&]() { return forward_part_a(e, c.s, p, false); }));
+    RC(run_graphed(e, (training & 1) ? 1 : 0, c.s, [&]() { return forward_part_a(e, c.s, p, false, tcur); }));
   }
   {
     const int Md = B * e->Lt, V = cfg.main.vocab;

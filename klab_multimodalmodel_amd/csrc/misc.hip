@@ -65,6 +65,62 @@ __global__ __launch_bounds__(256) void cast_pack_kernel(const CastDesc* __restri
   }
 }
 
+// ---- fused multi-tensor Adam with a compute-dtype shadow copy (math of torch.optim.Adam, ref/train.py:28) ----
+// One pass over the trainable tensors: p, g, m, v in (16-byte vectors), p, m, v out, and -- for GEMM weights -- the
+// bf16/f32 copy the next forward's GEMMs read, written straight into the engine's weight arena (the separate cast pass
+// over the masters disappears).  m / v live in flat buffers laid out like the flat gradient buffer.
+struct AdamDesc { float* p; long goff; long aoff; long n4_prefix; };  // aoff < 0: no arena copy
+struct AdamHyper { float lr_over_bc1, beta1, beta2, eps, weight_decay, inv_sqrt_bc2; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void adam_step_kernel(const AdamDesc* __restrict__ d, int nd, long total4, const float* __restrict__ grads,
+                                                        float* __restrict__ m, float* __restrict__ v, T* __restrict__ arena, AdamHyper h) {
+  constexpr int U = 4;
+  for (long g0 = ((long)blockIdx.x * U) * blockDim.x + threadIdx.x; g0 < total4; g0 += (long)gridDim.x * U * blockDim.x) {
+    int lo = 0, hi = nd - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (d[mid].n4_prefix <= g0) lo = mid; else hi = mid - 1;
+    }
+    f32x4 pv[U], gv[U], mv[U], vv[U];
+    float* pp[U]; long go[U]; long ao[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long g = g0 + (long)u * blockDim.x;
+      pp[u] = nullptr;
+      if (g < total4) {
+        while (lo + 1 < nd && d[lo + 1].n4_prefix <= g) ++lo;
+        const long local = (g - d[lo].n4_prefix) * 4;
+        pp[u] = d[lo].p + local; go[u] = d[lo].goff + local; ao[u] = d[lo].aoff < 0 ? -1 : d[lo].aoff + local;
+        pv[u] = *reinterpret_cast<const f32x4*>(pp[u]);
+        gv[u] = *reinterpret_cast<const f32x4*>(grads + go[u]);
+        mv[u] = *reinterpret_cast<const f32x4*>(m + go[u]);
+        vv[u] = *reinterpret_cast<const f32x4*>(v + go[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (pp[u]) {
+        f32x4 po, mo, vo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float g = gv[u][i] + h.weight_decay * pv[u][i];
+          mo[i] = mv[u][i] + (1.f - h.beta1) * (g - mv[u][i]);         // exp_avg.lerp_(grad, 1 - beta1)
+          vo[i] = h.beta2 * vv[u][i] + (1.f - h.beta2) * g * g;        // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+          const float denom = sqrtf(vo[i]) * h.inv_sqrt_bc2 + h.eps;
+          po[i] = pv[u][i] - h.lr_over_bc1 * (mo[i] / denom);
+        }
+        *reinterpret_cast<f32x4*>(pp[u]) = po;
+        *reinterpret_cast<f32x4*>(m + go[u]) = mo;
+        *reinterpret_cast<f32x4*>(v + go[u]) = vo;
+        if (ao[u] >= 0) {
+          if constexpr (sizeof(T) == 2) *reinterpret_cast<bf16x4*>(arena + ao[u]) = bf16x4{(bf16_t)po[0], (bf16_t)po[1], (bf16_t)po[2], (bf16_t)po[3]};
+          else *reinterpret_cast<f32x4*>(arena + ao[u]) = po;
+        }
+      }
+  }
+}
+
 // ---- embedding gather (+ T5 _shift_right, HF/t5:618-637) + input dropout (HF/t5:725) -----------
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restrict__ ids, int shift_right, int L, int start_id, int pad_id,
                                                         const float* __restrict__ table, int vocab, float* __restrict__ out, int rows, int d,
@@ -356,6 +412,23 @@ extern "C" int klab_cast_pack(const void* desc_dev, int ndesc, long total4, void
     hipLaunchKernelGGL(cast_pack_kernel<bf16_t>, dim3(stream_grid((total4 + 7) / 8)), dim3(256), 0, s, (const CastDesc*)desc_dev, ndesc, total4, (bf16_t*)dst);
   else
     hipLaunchKernelGGL(cast_pack_kernel<float>, dim3(stream_grid((total4 + 7) / 8)), dim3(256), 0, s, (const CastDesc*)desc_dev, ndesc, total4, (float*)dst);
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+
+extern "C" int klab_adam_step(const void* desc_dev, int ndesc, long total4, const float* grads, float* m, float* v, void* arena, int dtype,
+                              float lr, float beta1, float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,
+                              void* stream) {
+  if (!desc_dev || ndesc <= 0 || !grads || !m || !v || !arena || bias_corr1 <= 0.f || bias_corr2 <= 0.f) return KLAB_ERR_BADARG;
+  AdamHyper h{lr / bias_corr1, beta1, beta2, eps, weight_decay, 1.f / sqrtf(bias_corr2)};
+  hipStream_t s = (hipStream_t)stream;
+  static const int cap = [] { const char* e = getenv("KLAB_ADAM_GRID"); return e ? atoi(e) : 1024; }();
+  long gl = ((total4 + 3) / 4 + 255) / 256;
+  const unsigned grid = (unsigned)(gl < 1 ? 1 : (gl > cap ? cap : gl));
+  if (dtype == KLAB_BF16)
+    hipLaunchKernelGGL(adam_step_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const AdamDesc*)desc_dev, ndesc, total4, grads, m, v, (bf16_t*)arena, h);
+  else
+    hipLaunchKernelGGL(adam_step_kernel<float>, dim3(grid), dim3(256), 0, s, (const AdamDesc*)desc_dev, ndesc, total4, grads, m, v, (float*)arena, h);
   KLAB_LAUNCH_CHECK();
   return KLAB_OK;
 }

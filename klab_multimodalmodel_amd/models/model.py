@@ -96,7 +96,7 @@ class _LossFn(torch.autograd.Function):
     def forward(ctx, model, want_grad, pixels, src, tgt, *params):
         eng = model._engine_for(pixels, src, tgt)
         # the engine keeps a device-side counter RNG: the base only (re)seeds it, every forward advances it
-        eng.forward(pixels, src, tgt, training=int(model.transformer.training) | (2 if model._frozen_unchanged() else 0),
+        eng.forward(pixels, src, tgt, training=int(model.transformer.training) | (2 if model._frozen_unchanged() else 0) | (4 if model._trainable_current() else 0),
                     seed=model._seed_base, want_grad=want_grad)
         ctx.model = model
         ctx.eng = eng
@@ -213,7 +213,11 @@ class MyModel(nn.Module):
         self._seed_base = torch.initial_seed() & 0xFFFFFFFF
         self._seed_ctr = 0
         self._frozen_fp = None
+        self._train_fp = None  # version fingerprint of the trainable T5 right after a klab FusedAdam step (bf16 copies current)
         self._fwd_token = 0
+        import weakref
+        for p in self.transformer.parameters():  # lets klab_multimodalmodel_amd.optim.FusedAdam find its engine
+            p._klab_owner = weakref.ref(self)
 
     # ---- weights -----------------------------------------------------------------------------
     @staticmethod
@@ -273,7 +277,22 @@ class MyModel(nn.Module):
             eng.set_graph(self.use_graph)
             self._bound_key = key
             self._frozen_fp = None
+            self._train_fp = None
         return self._engine
+
+    def _note_optimizer_step(self):
+        """called by optim.FusedAdam: the step kernel rewrote the masters AND their compute-dtype copies."""
+        self._train_fp = sum(p._version for p in self.transformer.parameters())
+
+    def _trainable_current(self):
+        """True when nothing wrote the trainable T5 since the last fused optimizer step (tensor version counters) and the
+        engine was not re-bound: the forward may then skip its fp32 -> bf16 weight cast."""
+        if self._train_fp is None:
+            return False
+        if sum(p._version for p in self.transformer.parameters()) != self._train_fp:
+            self._train_fp = None
+            return False
+        return True
 
     def _frozen_unchanged(self):
         """True when no frozen-tower parameter was written since the previous forward (tensor version counters):

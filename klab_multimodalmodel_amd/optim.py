@@ -1,0 +1,137 @@
+"""Fused Adam for the native MyModel.
+
+Drop-in for the reference's `torch.optim.Adam(model.module.transformer.parameters(), lr=args.lr)` (ref/train.py:28): same
+constructor arguments, same update rule (no amsgrad, L2 weight decay), `param_groups` / LR schedulers / `zero_grad` /
+`state_dict` as usual.  When every parameter belongs to one klab MyModel whose gradients live in the engine's flat buffer
+(the direct-gradient mode that `MyModel._direct_grads` / klab DDP use), `step()` is ONE kernel over all tensors that also
+rewrites the bf16 copies the next forward's GEMMs read -- the engine's separate fp32->bf16 cast pass is skipped.  In every
+other situation (foreign parameters, several param groups with different hyper-parameters, amsgrad, gradients that are not
+views of the flat buffer) it silently delegates to `torch.optim.Adam`, so it is always safe to use.
+"""
+import weakref
+
+import torch
+from torch.optim import Adam as _TorchAdam
+from torch.optim import Optimizer
+
+
+class FusedAdam(Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, *, maximize=False):
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
+            raise ValueError("invalid Adam hyper-parameter")
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, maximize=maximize)
+        super().__init__(params, defaults)
+        self._steps = 0
+        self._m = self._v = None
+        self._owner = None
+        self._fallback = None
+        self._fb_reason = None
+
+    # ---- which model owns these parameters -------------------------------------------------------------------------
+    def _find_owner(self):
+        owner = None
+        for g in self.param_groups:
+            for p in g["params"]:
+                ref = getattr(p, "_klab_owner", None)
+                m = ref() if ref is not None else None
+                if m is None or (owner is not None and m is not owner):
+                    return None
+                owner = m
+        return owner
+
+    def _fast_ok(self):
+        """(model, None) when the one-kernel path applies, else (None, reason)."""
+        if len(self.param_groups) != 1:
+            return None, "several param groups"
+        g = self.param_groups[0]
+        if g["amsgrad"] or g["maximize"]:
+            return None, "amsgrad / maximize"
+        model = self._find_owner()
+        if model is None:
+            return None, "parameters not owned by one klab MyModel"
+        if model._flat.get("main") is None or model._engine.shape is None:
+            return None, "engine not bound yet"
+        views = {id(p): v for p, v, mn in (model._views or []) if mn == "main"}
+        mine = {id(p) for p in g["params"]}
+        if mine != {id(p) for p in model.transformer.ordered() if p.requires_grad} or set(views) != mine:
+            return None, "not exactly the trainable T5 parameters"
+        for p in g["params"]:
+            v = views[id(p)]
+            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                return None, "gradients are not views of the flat buffer"
+        return model, None
+
+    # ---- torch.optim API --------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        model, why = (None, "fallback already active") if self._fallback is not None else self._fast_ok()
+        if model is None:
+            self._fb_reason = why
+            self._step_fallback()
+            return loss
+        g = self.param_groups[0]
+        flat = model._flat["main"]
+        if self._m is None or self._m.shape != flat.shape or self._m.device != flat.device:
+            self._m = torch.zeros_like(flat)
+            self._v = torch.zeros_like(flat)
+        self._steps += 1
+        b1, b2 = g["betas"]
+        model._engine.adam_step(self._m, self._v, float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]),
+                                1.0 - b1 ** self._steps, 1.0 - b2 ** self._steps)
+        model._note_optimizer_step()
+        self._owner = weakref.ref(model)
+        return loss
+
+    def _step_fallback(self):
+        if self._fallback is None:
+            self._fallback = _TorchAdam(self.param_groups, fused=all(p.is_cuda for g in self.param_groups for p in g["params"]) or None)
+            self._fallback.param_groups = self.param_groups  # share the group dicts (LR schedulers act on ours)
+            if self._m is not None:  # carry the fused state over (one-way)
+                model = self._owner() if self._owner is not None else None
+                if model is not None:
+                    for p, v, mn in model._views:
+                        if mn != "main" or not p.requires_grad:
+                            continue
+                        off = v.storage_offset()
+                        self._fallback.state[p] = {
+                            "step": torch.tensor(float(self._steps), device=p.device if self._fallback.defaults.get("fused") else "cpu"),
+                            "exp_avg": self._m[off:off + p.numel()].view(p.shape).clone(),
+                            "exp_avg_sq": self._v[off:off + p.numel()].view(p.shape).clone()}
+        self._fallback.step()
+
+    def state_dict(self):
+        """torch.optim.Adam-compatible: per-parameter `step`, `exp_avg`, `exp_avg_sq` (copies)."""
+        if self._fallback is not None:
+            return self._fallback.state_dict()
+        model = self._owner() if self._owner is not None else None
+        if model is not None and self._m is not None:
+            for p, v, mn in model._views:
+                if mn == "main" and p.requires_grad:
+                    off = v.storage_offset()
+                    self.state[p] = {"step": torch.tensor(float(self._steps)),
+                                     "exp_avg": self._m[off:off + p.numel()].view(p.shape).clone(),
+                                     "exp_avg_sq": self._v[off:off + p.numel()].view(p.shape).clone()}
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        model = self._find_owner()
+        steps = 0
+        if model is not None and model._views:
+            flat = model._flat["main"]
+            self._m, self._v = torch.zeros_like(flat), torch.zeros_like(flat)
+            for p, v, mn in model._views:
+                st = self.state.get(p)
+                if mn != "main" or not st:
+                    continue
+                off = v.storage_offset()
+                self._m[off:off + p.numel()].view(p.shape).copy_(st["exp_avg"])
+                self._v[off:off + p.numel()].view(p.shape).copy_(st["exp_avg_sq"])
+                steps = max(steps, int(float(st["step"])))
+            self._owner = weakref.ref(model)
+        self._steps = steps
+        self._fallback = None

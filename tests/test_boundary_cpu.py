@@ -194,3 +194,20 @@ def test_host_tables_match_oracle():
         ct, ix = swin_cpb_tables(w, pw)
         rt, ri = O.swin_coords_table_and_index(w, pw, torch.float32)
         assert torch.equal(ct, rt.view(-1, 2)) and torch.equal(ix.long(), ri.view(-1))
+
+
+def test_fused_adam_falls_back_to_torch_adam_for_foreign_parameters():
+    """optim.FusedAdam is always safe to use: parameters that do not belong to a klab MyModel get torch.optim.Adam's update."""
+    import torch
+    from klab_multimodalmodel_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    w0 = torch.randn(7, 5)
+    a, b = torch.nn.Parameter(w0.clone()), torch.nn.Parameter(w0.clone())
+    oa, ob = torch.optim.Adam([a], lr=1e-2, weight_decay=0.1), FusedAdam([b], lr=1e-2, weight_decay=0.1)
+    for _ in range(3):
+        for p, o in ((a, oa), (b, ob)):
+            (p ** 2).sum().backward()
+            o.step()
+            o.zero_grad()
+    assert ob._fallback is not None
+    assert torch.equal(a.detach(), b.detach())
