@@ -24,6 +24,9 @@ def main(path):
         pending = set()   # registers written by ds_read since the last lgkmcnt wait
         for l in body[i0:i1]:
             t = l.strip()
+            if t.startswith(".LBB"):  # basic-block boundary: control may arrive from a path with other live registers;
+                pending = set()       # the hand-scheduled loops keep every asm load and its wait inside one block
+                continue
             if not t or t.startswith(";") or t.startswith("."): continue
             op, _, rest = t.partition(" ")
             ops = [o.strip() for o in rest.split(",")]
