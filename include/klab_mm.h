@@ -181,6 +181,9 @@ int klab_gelu_fwd(const void* x, void* y, int dtype, long n, void* stream);
  *   out[M,C] = shortcut + LayerNorm(fc2(GELU(fc1(x) + b1)) + b2) * gamma + beta,  outt = bf16(out) (optional)
  * x [M,C], w1 [4C,C], w2 [C,4C] in `dtype` (bf16 only), everything else f32.  C in {64, 128}; other widths return
  * KLAB_ERR_UNSUPPORTED and the caller keeps the three-kernel path (klab_gemm x2 + klab_layernorm_fwd). */
+/* ... and of the attention half's tail, HF/swinv2:496-506 + 697-700: out = shortcut + LayerNorm(x Wp^T + bp) * gamma + beta */
+int klab_swin_proj_ln_fused(const void* x, const float* shortcut, const void* w, const float* b, const float* gamma, const float* beta,
+                            float* out, void* outt, int dtype, int M, int C, float eps, void* stream);
 int klab_swin_mlp_fused(const void* x, const float* shortcut, const void* w1, const float* b1, const void* w2, const float* b2,
                         const float* gamma, const float* beta, float* out, void* outt, int dtype, int M, int C, float eps,
                         void* stream);

@@ -801,9 +801,17 @@ int swin_forward(const Ctx& c, const float* pixels, float p_in, bool refresh_bia
       a.dtype = c.dt; a.qkv = q.qkv; a.ctx = q.ctx; a.bias = q.bias; a.logit_scale = W[ix.ls]; a.lse = q.lse;
       a.B = B; a.R = q.R; a.w = q.w; a.shift = q.shift; a.H = q.H; a.C = C;
       RC(klab_swin_attn_fwd(&a, c.ws()));
-      RC(linear_fwd(c, q.ctx, M, C, P[ix.pw].warena_off, C, q.po, C, c.dt, W[ix.pb]));
-      RC(klab_layernorm_fwd(q.po, c.dt, W[ix.ln1w], W[ix.ln1b], x, q.h1, q.h1t, c.dt, q.mean1, q.rstd1, M, C, s.ln_eps, 0, 0, 0, 0.f,
-                            nullptr, 0, c.ws()));
+      static const bool fused_proj = [] { const char* v = getenv("KLAB_SWIN_FUSED_PROJ"); return !v || atoi(v) != 0; }();
+      int prc = KLAB_ERR_UNSUPPORTED;
+      if (!e->cfg.train_swin && fused_proj)  // frozen tower, narrow stage: output projection + LayerNorm + residual in one kernel
+        prc = klab_swin_proj_ln_fused(q.ctx, x, woff(c, P[ix.pw].warena_off), W[ix.pb], W[ix.ln1w], W[ix.ln1b], q.h1, q.h1t, c.dt, M, C, s.ln_eps,
+                                      c.ws());
+      if (prc != 0 && prc != KLAB_ERR_UNSUPPORTED) return prc;
+      if (prc != 0) {
+        RC(linear_fwd(c, q.ctx, M, C, P[ix.pw].warena_off, C, q.po, C, c.dt, W[ix.pb]));
+        RC(klab_layernorm_fwd(q.po, c.dt, W[ix.ln1w], W[ix.ln1b], x, q.h1, q.h1t, c.dt, q.mean1, q.rstd1, M, C, s.ln_eps, 0, 0, 0, 0.f,
+                              nullptr, 0, c.ws()));
+      }
       if (e->cfg.train_swin) {  // keep the pre-activation for gelu'
         RC(linear_fwd(c, q.h1t, M, C, P[ix.f1w].warena_off, F, q.z, F, c.dt, W[ix.f1b]));
         RC(klab_gelu_fwd(q.z, q.a, c.dt, (long)M * F, c.ws()));

@@ -46,15 +46,17 @@ struct MlpP {
 // K-major LDS image of ROWS x 32 k (64-B rows), 16-B chunk c of row r at position c ^ 2*((r>>2)&1) (as in gemm.hip)
 __device__ __forceinline__ int img_off(int r, int chunk) { return r * 64 + ((chunk ^ (((r >> 2) & 1) << 1)) * 16); }
 
-template <int C, int S>
+// PROJ: the attention half's tail instead -- out = shortcut + LayerNorm(x Wp^T + bp) * gamma + beta (HF/swinv2:496-506,
+// 697-700): the "hidden" layer IS the output (width C, no GELU, no second GEMM); w1/b1 carry the projection.
+template <int C, int S, bool PROJ = false>
 __global__ __launch_bounds__(256) void swin_mlp_fused_kernel(MlpP p) {
-  constexpr int HD = 4 * C, HC = 64, NCH = HD / HC;       // hidden width, hidden units per chunk, chunks
+  constexpr int HD = PROJ ? C : 4 * C, HC = 64, NCH = HD / HC;  // hidden width, hidden units per chunk, chunks
   constexpr int KB1 = C / 32;                             // 32-deep k blocks of fc1
   constexpr int CT = C / 16;                              // 16-channel output tiles of fc2
   constexpr int W1B = KB1 * HC * 64;                      // bytes of a W1 chunk: KB1 images of [64 rows x 32 k]
-  constexpr int W2B = 2 * C * 64;                         // bytes of a W2 chunk: 2 images of [C rows x 32 k]
+  constexpr int W2B = PROJ ? 0 : 2 * C * 64;              // bytes of a W2 chunk: 2 images of [C rows x 32 k]
   constexpr int SLOT = W1B + W2B;
-  constexpr int DMA1 = KB1, DMA2 = 2 * (C / 64), LPS = DMA1 + DMA2;  // LDS-DMA instructions per wave per chunk
+  constexpr int DMA1 = KB1, DMA2 = PROJ ? 0 : 2 * (C / 64), LPS = DMA1 + DMA2;  // LDS-DMA instructions per wave per chunk
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* b1s = reinterpret_cast<float*>(smem + S * SLOT);  // fc1 bias, HD floats
   const unsigned b1a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + S * SLOT;
@@ -73,6 +75,7 @@ __global__ __launch_bounds__(256) void swin_mlp_fused_kernel(MlpP p) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(base + kb * (HC * 64) + wave * 1024), 16, 0, 0);
     }
+    if constexpr (!PROJ)
 #pragma unroll
     for (int pq = 0; pq < 2; ++pq)      // W2 image pq: rows = channels, k = hidden units ch*64 + 32*pq + [0,32)
 #pragma unroll
@@ -148,6 +151,13 @@ __global__ __launch_bounds__(256) void swin_mlp_fused_kernel(MlpP p) {
           acc1[1][j2 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, xf[1][kb], acc1[1][j2 + jj], 0, 0, 0);
         }
     }
+    if constexpr (PROJ) {  // the chunk's 64 "hidden units" are output channels 64 ch .. 64 ch + 63
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) acc2[mi][ch * 4 + j] = acc1[mi][j] + b1r[j >> 1][j & 1];
+      continue;
+    }
     // ---- bias + GELU, packed as the next MFMA's B operand (hidden units 32 pq + {4g..4g+3, 16+4g..16+4g+3}) ----
     bf16x8 hf[2][2];
 #pragma unroll
@@ -195,7 +205,8 @@ __global__ __launch_bounds__(256) void swin_mlp_fused_kernel(MlpP p) {
     float sum = 0.f;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(p.b2 + ct * 16 + g * 4);
+      f32x4 bb = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (!PROJ) bb = *reinterpret_cast<const f32x4*>(p.b2 + ct * 16 + g * 4);
 #pragma unroll
       for (int i = 0; i < 4; ++i) { acc2[mi][ct][i] += bb[i]; sum += acc2[mi][ct][i]; }
     }
@@ -224,13 +235,13 @@ __global__ __launch_bounds__(256) void swin_mlp_fused_kernel(MlpP p) {
   }
 }
 
-template <int C, int S>
+template <int C, int S, bool PROJ = false>
 int launch_mlp(const MlpP& p, hipStream_t s) {
-  constexpr int SLOT = (C / 32) * 64 * 64 + 2 * C * 64;
-  const size_t lds = (size_t)S * SLOT + 4 * C * 4;
-  const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(swin_mlp_fused_kernel<C, S>), lds);
+  constexpr int SLOT = (C / 32) * 64 * 64 + (PROJ ? 0 : 2 * C * 64);
+  const size_t lds = (size_t)S * SLOT + (PROJ ? C : 4 * C) * 4;
+  const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(swin_mlp_fused_kernel<C, S, PROJ>), lds);
   if (rc) return rc;
-  hipLaunchKernelGGL((swin_mlp_fused_kernel<C, S>), dim3((unsigned)((p.M + 127) / 128)), dim3(256), lds, s, p);
+  hipLaunchKernelGGL((swin_mlp_fused_kernel<C, S, PROJ>), dim3((unsigned)((p.M + 127) / 128)), dim3(256), lds, s, p);
   KLAB_LAUNCH_CHECK();
   return KLAB_OK;
 }
@@ -249,4 +260,16 @@ extern "C" int klab_swin_mlp_fused(const void* x, const float* shortcut, const v
   if (C == 64) return launch_mlp<64, 3>(p, (hipStream_t)stream);
   if (C == 128) return launch_mlp<128, 2>(p, (hipStream_t)stream);
   return KLAB_ERR_UNSUPPORTED;  // wider stages keep the three-kernel path (their weights do not fit the streaming budget)
+}
+
+extern "C" int klab_swin_proj_ln_fused(const void* x, const float* shortcut, const void* w, const float* b, const float* gamma,
+                                       const float* beta, float* out, void* outt, int dtype, int M, int C, float eps, void* stream) {
+  using namespace klab;
+  if (!x || !shortcut || !w || !b || !gamma || !beta || !out) return KLAB_ERR_BADARG;
+  if (dtype != KLAB_BF16) return KLAB_ERR_UNSUPPORTED;
+  if (M <= 0) return KLAB_OK;
+  MlpP p{(const bf16_t*)x, shortcut, (const bf16_t*)w, b, nullptr, nullptr, gamma, beta, out, (bf16_t*)outt, M, eps};
+  if (C == 64) return launch_mlp<64, 2, true>(p, (hipStream_t)stream);
+  if (C == 128) return launch_mlp<128, 2, true>(p, (hipStream_t)stream);
+  return KLAB_ERR_UNSUPPORTED;
 }

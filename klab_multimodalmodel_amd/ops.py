@@ -67,6 +67,14 @@ def layernorm_fwd(y, gamma, beta, shortcut=None, out=None, outt=None, mean=None,
                                    L.stream_ptr()), "klab_layernorm_fwd")
 
 
+def swin_proj_ln_fused(x, shortcut, w, b, gamma, beta, out, outt=None, eps=1e-5):
+    """out = shortcut + LN(x @ w.T + b)*gamma+beta (frozen Swin-V2 attention-output half, C in {64,128})."""
+    lib = L.load()
+    M, Cc = x.shape
+    L.check(lib.klab_swin_proj_ln_fused(x.data_ptr(), shortcut.data_ptr(), w.data_ptr(), b.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                        out.data_ptr(), L.ptr(outt), L.dtype_code(x.dtype), M, Cc, eps, L.stream_ptr()), "klab_swin_proj_ln_fused")
+
+
 def swin_mlp_fused(x, shortcut, w1, b1, w2, b2, gamma, beta, out, outt=None, eps=1e-5):
     """out = shortcut + LN(fc2(GELU(fc1(x)+b1))+b2)*gamma+beta (frozen Swin-V2 MLP half, C in {64,128}); raises
     NotImplementedError for other widths (HF/swinv2:539-563, 697-702)."""

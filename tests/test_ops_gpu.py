@@ -493,3 +493,21 @@ def test_swin_mlp_fused_matches_torch(ops, M, Cc):
                                torch.zeros(1024, device="cuda"), torch.zeros(256, 1024, device="cuda", dtype=torch.bfloat16),
                                torch.zeros(256, device="cuda"), torch.ones(256, device="cuda"), torch.zeros(256, device="cuda"),
                                torch.empty(8, 256, device="cuda"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,Cc", [(300, 64), (1000, 128)])
+def test_swin_proj_ln_fused_matches_torch(ops, M, Cc):
+    """Fused frozen-tower attention-output half == Linear -> LayerNorm -> + shortcut in fp32 torch (HF/swinv2:496-506, 697-700)."""
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(M, Cc, generator=g).to(torch.bfloat16)
+    sc = torch.randn(M, Cc, generator=g)
+    w = (torch.randn(Cc, Cc, generator=g) / Cc ** 0.5).to(torch.bfloat16)
+    b = torch.randn(Cc, generator=g) * 0.1
+    gm, bt = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.1
+    ref = sc + F.layer_norm(x.float() @ w.float().t() + b, (Cc,), gm, bt, 1e-5)
+    out = torch.empty(M, Cc, device="cuda")
+    outt = torch.empty(M, Cc, device="cuda", dtype=torch.bfloat16)
+    ops.swin_proj_ln_fused(dev(x), dev(sc), dev(w), dev(b), dev(gm), dev(bt), out, outt, eps=1e-5)
+    assert rel_l2(out.cpu(), ref) < 1e-3
+    assert rel_l2(outt.float().cpu(), ref) < 6e-3
