@@ -861,12 +861,18 @@ static int dispatch_tile(GemmP& p, bool atomic_ok, hipStream_t s) {
   p.splits = 1;
   if (atomic_ok && nt >= 256 && p.M >= 128 && p.N >= 64 && tiles(128, 64) < 1024) {
     // very long K over few tiles (LM-head dgrad: K = vocabulary): one workgroup per CU streams its operands from HBM
-    // with too little in flight; split K so that ~4 workgroups share a CU
-    const long t = tiles(128, 64);
+    // with too little in flight; split K so that ~4 workgroups share a CU.  128x128 tiles when N allows: the streamed
+    // operand (263 MB of dlogits) is re-read once per column tile, i.e. 4x instead of 8x for N = 512.
+    static const int lk = [] { const char* e = getenv("KLAB_GEMM_LONGK_TILE"); return e ? atoi(e) : 128; }();
+    const bool wide = lk == 128 && p.N >= 128;
+    const long t = wide ? tiles(128, 128) : tiles(128, 64);
     long sp = (1024 + t - 1) / t;
     if (sp > nt / 64) sp = nt / 64;
     if (sp > 16) sp = 16;
-    if (sp >= 2) { p.splits = (int)sp; return dispatch_layout<T, 128, 64>(p, true, s); }
+    if (sp >= 2) {
+      p.splits = (int)sp;
+      return wide ? dispatch_layout<T, 128, 128>(p, true, s) : dispatch_layout<T, 128, 64>(p, true, s);
+    }
   }
   if (tiles(128, 128) >= 240) return dispatch_layout<T, 128, 128>(p, false, s);
   if (tiles(128, 64) >= 240) return dispatch_layout<T, 128, 64>(p, false, s);
