@@ -141,6 +141,11 @@ typedef struct klab_swin_attn_args {
   const void* dctx; void* dqkv; float* dbias; float* dlogit_scale;
 } klab_swin_attn_args;
 int klab_swin_attn_fwd(const klab_swin_attn_args* a, void* stream);
+/* Frozen tower (forward only): the q|k|v projection fused into the window attention, HF/swinv2:389-455 in one kernel.
+ * x [B*R*R, C] (the block's LN'd input), wqkv [3C, C] rows q|k|v, bqkv [3C] f32 (k part zero) or NULL, ctx [B*R*R, C].
+ * bf16, head dim 32, C in {64, 128}, w*w <= 64; otherwise KLAB_ERR_UNSUPPORTED (caller: klab_gemm + klab_swin_attn_fwd). */
+int klab_swin_qkv_attn_fused(const void* x, const void* wqkv, const float* bqkv, void* ctx, const float* bias, const float* logit_scale,
+                             int dtype, int B, int R, int w, int shift, int H, int C, void* stream);
 int klab_swin_attn_bwd(const klab_swin_attn_args* a, void* stream);
 /* continuous position bias (HF/swinv2:376-378,418-428): coords [(2w-1)^2,2], index [n*n] are the
  * input-independent buffers of HF/swinv2:457-492; table [(2w-1)^2,H] and hidden [(2w-1)^2,512]

@@ -282,6 +282,165 @@ __global__ __launch_bounds__(64) void swin_attn_fwd_mfma32(SwinAttnP p) {
   }
 }
 
+// ---- frozen tower: QKV projection fused into the window attention (bf16, head dim 32, windows <= 64 tokens, C = 64 / 128) ----
+// One wave per (image, window, head) computes its head's q | k | v = x_win Wqkv_h^T + b from the window's LN'd input rows
+// (swapped MFMA: a lane gets 4 consecutive features of token lane&15), normalises q and k in fp32, parks K-hat / V in its
+// private LDS images and keeps Q-hat in registers: two 16-feature tiles of a token are exactly the B operand of the
+// score MFMA in the permuted feature order kappa(g, j) = 16 (j >> 2) + 4 g + (j & 3), so K-hat fragments are read in that
+// order too.  The [M, 3C] q|k|v tensor (77 MB written and read back per stage-0 block at B = 64) never exists.
+struct SwinQkvP {
+  const bf16_t* x; const bf16_t* wqkv; const float* bqkv;  // x [M, C]; wqkv [3C, C] rows q | k | v; bqkv [3C] (k part zero) or null
+  bf16_t* ctx; const float* bias; const float* logit_scale;
+  int B, R, w, shift, H;
+};
+
+template <int C>
+__global__ __launch_bounds__(64) void swin_qkv_attn_fused(SwinQkvP p) {
+  constexpr int HD = 32, KP = 80, KB = C / 32;
+  __shared__ __attribute__((aligned(16))) char Kr[64 * KP];
+  __shared__ __attribute__((aligned(16))) char Vt[8 * 896];
+  __shared__ int tok[64];
+  __shared__ int reg[64];
+  const int w = p.w, n = w * w, R = p.R, H = p.H;
+  const int nWr = R / w, nW = nWr * nWr;
+  const int lane = threadIdx.x, g = lane >> 4, lr = lane & 15;
+  int bid = blockIdx.x;
+  const int h = bid % H; bid /= H;
+  const int win = bid % nW; const int b = bid / nW;
+  const int wy = win / nWr, wx = win % nWr;
+  {  // token index + shift-mask region of window slot `lane`
+    int t = 0, rg = -1;
+    if (lane < n) {
+      const int ys = wy * w + lane / w, xs = wx * w + lane % w;
+      const int y = (ys + p.shift) % R, x = (xs + p.shift) % R;
+      t = (b * R + y) * R + x;
+      rg = p.shift > 0 ? swin_region(ys, R, w, p.shift) * 3 + swin_region(xs, R, w, p.shift) : 0;
+    }
+    tok[lane] = t; reg[lane] = rg;
+  }
+  // this head's 96 weight rows as MFMA A fragments (row = lane&15 of the tile, k = 32 kb + 8 g ..): tiles q0 q1 k0 k1 v0 v1
+  bf16x8 wf[6][KB];
+  f32x4 bq[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int row = (j >> 1) * C + h * HD + (j & 1) * 16;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) wf[j][kb] = *reinterpret_cast<const bf16x8*>(p.wqkv + (long)(row + lr) * C + kb * 32 + g * 8);
+    bq[j] = p.bqkv ? *reinterpret_cast<const f32x4*>(p.bqkv + row + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  bf16x8 qh[4];  // Q-hat of the 4 query tiles, kappa feature order
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int j0 = mt * 16 + lr;                       // window slot of this lane's token
+    const int t = tok[j0 < n ? j0 : n - 1];
+    bf16x8 xf[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) xf[kb] = *reinterpret_cast<const bf16x8*>(p.x + (long)t * C + kb * 32 + g * 8);
+    f32x4 d[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      d[j] = bq[j];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) d[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][kb], xf[kb], d[j], 0, 0, 0);
+    }
+    // d[j][r] = feature 16 (j&1) + 4 g + r of q / k / v for token j0.  L2 norms over the 32 features: in-lane + lane groups
+    float sq = 0.f, sk = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { sq += d[0][r] * d[0][r] + d[1][r] * d[1][r]; sk += d[2][r] * d[2][r] + d[3][r] * d[3][r]; }
+    sq += __shfl_xor(sq, 16, 64); sq += __shfl_xor(sq, 32, 64);
+    sk += __shfl_xor(sk, 16, 64); sk += __shfl_xor(sk, 32, 64);
+    const float iq = 1.f / fmaxf(sqrtf(sq), 1e-12f), ik = 1.f / fmaxf(sqrtf(sk), 1e-12f);
+    qh[mt] = bf16x8{(bf16_t)(d[0][0] * iq), (bf16_t)(d[0][1] * iq), (bf16_t)(d[0][2] * iq), (bf16_t)(d[0][3] * iq),
+                    (bf16_t)(d[1][0] * iq), (bf16_t)(d[1][1] * iq), (bf16_t)(d[1][2] * iq), (bf16_t)(d[1][3] * iq)};
+    const bool valid = j0 < n;  // padded slots: zero K-hat / V rows (their scores are masked to -inf anyway)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int col = hf * 16 + g * 4;
+      bf16x4 kk = {(bf16_t)(d[2 + hf][0] * ik), (bf16_t)(d[2 + hf][1] * ik), (bf16_t)(d[2 + hf][2] * ik), (bf16_t)(d[2 + hf][3] * ik)};
+      bf16x4 vv = {(bf16_t)d[4 + hf][0], (bf16_t)d[4 + hf][1], (bf16_t)d[4 + hf][2], (bf16_t)d[4 + hf][3]};
+      if (!valid) { kk = bf16x4{}; vv = bf16x4{}; }
+      *reinterpret_cast<bf16x4*>(Kr + j0 * KP + col * 2) = kk;
+      *reinterpret_cast<bf16x4*>(Vt + swin_tr_off(j0, col)) = vv;
+    }
+  }
+  __syncthreads();
+  const float scale = __expf(fminf(p.logit_scale[h], 4.6051701859880914f));
+  auto fetch_bias = [&](int qt, f32x4 (&bv)[4]) {
+    const int q = qt * 16 + lr;
+    const float* brow = p.bias + ((long)h * n + (q < n ? q : n - 1)) * n;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int key = t * 16 + g * 4 + r; bv[t][r] = brow[key < n ? key : n - 1]; }
+  };
+  const int nqt = (n + 15) / 16;
+  f32x4 bnext[4];
+  fetch_bias(0, bnext);
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt) {
+    if (qt >= nqt) break;
+    const int q = qt * 16 + lr;
+    const int qc = q < n ? q : n - 1;
+    const int tq = tok[qc], rq = reg[qc];
+    f32x4 bcur[4] = {bnext[0], bnext[1], bnext[2], bnext[3]};
+    if (qt + 1 < nqt) fetch_bias(qt + 1, bnext);
+    f32x4 st[4];
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      // K-hat fragment in kappa order: features 4g..4g+3 and 16+4g..16+4g+3 of key row t*16 + lane&15
+      const char* krow = Kr + (t * 16 + lr) * KP;
+      const bf16x4 lo = *reinterpret_cast<const bf16x4*>(krow + g * 8), hi = *reinterpret_cast<const bf16x4*>(krow + 32 + g * 8);
+      const bf16x8 kf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qh[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = t * 16 + g * 4 + r;
+        float x = -INFINITY;
+        if (key < n) {
+          x = st[t][r] * scale + bcur[t][r];
+          if (reg[key] != rq) x += -200.f;  // -100 twice (HF/swinv2:433-436)
+        }
+        st[t][r] = x;
+        m = fmaxf(m, x);
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float e = __expf(st[t][r] - m); st[t][r] = e; sum += e; }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+    f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      const f32x4 a = st[2 * sidx], bb = st[2 * sidx + 1];
+      const bf16x8 pf = {(bf16_t)(a[0] * inv), (bf16_t)(a[1] * inv), (bf16_t)(a[2] * inv), (bf16_t)(a[3] * inv),
+                         (bf16_t)(bb[0] * inv), (bf16_t)(bb[1] * inv), (bf16_t)(bb[2] * inv), (bf16_t)(bb[3] * inv)};
+      const int q4 = lr >> 2, pp = lane & 3;
+      const int r0 = sidx * 32 + 4 * g + q4;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_sw*)(Vt + swin_tr_off(r0, dt * 16 + 4 * pp)));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_sw*)(Vt + swin_tr_off(r0 + 16, dt * 16 + 4 * pp)));
+        const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+      }
+    }
+    if (q < n) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+        *reinterpret_cast<bf16x4*>(p.ctx + (long)tq * C + h * HD + dt * 16 + g * 4) =
+            bf16x4{(bf16_t)o[dt][0], (bf16_t)o[dt][1], (bf16_t)o[dt][2], (bf16_t)o[dt][3]};
+    }
+  }
+}
+
 // Backward of the same (used when --image_model_train, ref/models/model.py:15): lane i owns query row
 // i, recomputes P from the saved lse; dK-hat / dV are accumulated in LDS with f32 atomics (ds_add_f32),
 // then pushed through the L2-normalisation Jacobian.  d(logit_scale) and d(bias) use global atomics.
@@ -599,6 +758,20 @@ extern "C" int klab_swin_cpb_bias_bwd(const float* dbias, const float* bias, con
   hipLaunchKernelGGL(cpb_dtable_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, dbias, bias, index, dtable, heads, n * n);
   KLAB_LAUNCH_CHECK();
   hipLaunchKernelGGL(cpb_mlp_bwd_kernel, dim3((nhidden + 255) / 256), dim3(256), 0, s, dtable, coords, hidden, w2, dw0, db0, dw2, ntab, heads, nhidden);
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+
+extern "C" int klab_swin_qkv_attn_fused(const void* x, const void* wqkv, const float* bqkv, void* ctx, const float* bias, const float* logit_scale,
+                                        int dtype, int B, int R, int w, int shift, int H, int C, void* stream) {
+  if (!x || !wqkv || !ctx || !bias || !logit_scale || B <= 0 || R <= 0 || w <= 0 || H <= 0) return KLAB_ERR_BADARG;
+  if (dtype != KLAB_BF16 || C != H * 32 || w * w > 64 || R % w || shift < 0 || shift >= w) return KLAB_ERR_UNSUPPORTED;
+  SwinQkvP p{(const bf16_t*)x, (const bf16_t*)wqkv, bqkv, (bf16_t*)ctx, bias, logit_scale, B, R, w, shift, H};
+  const int nW = (R / w) * (R / w);
+  hipStream_t s = (hipStream_t)stream;
+  if (C == 64) hipLaunchKernelGGL(swin_qkv_attn_fused<64>, dim3(B * nW * H), dim3(64), 0, s, p);
+  else if (C == 128) hipLaunchKernelGGL(swin_qkv_attn_fused<128>, dim3(B * nW * H), dim3(64), 0, s, p);
+  else return KLAB_ERR_UNSUPPORTED;
   KLAB_LAUNCH_CHECK();
   return KLAB_OK;
 }

@@ -136,6 +136,7 @@ struct klab_engine {
   struct GraphSlot { hipGraphExec_t exec = nullptr; int uses = 0; bool failed = false; } gs[7];
   // engine-owned copies of the per-step inputs: graph nodes need stable addresses
   float* pixels_buf = nullptr; long long *src_buf = nullptr, *tgt_buf = nullptr; float* dloss_buf = nullptr;
+  const float* pixels_cur = nullptr;  // what this forward's patch embedding reads: the caller's tensor, or pixels_buf under graph replay
   uint32_t seed_base = 0; bool seed_set = false;
   // probe: HIP events around the LM-head GEMM of each forward
   bool probe_on = false; std::vector<hipEvent_t> ev0, ev1; int probe_n = 0;
@@ -795,12 +796,20 @@ int swin_forward(const Ctx& c, const float* pixels, float p_in, bool refresh_bia
                               e->swin_ntab[st], n, q.H, 512, c.ws()));
       const float* qkvb = ix.qb >= 0 ? e->farena + bias_off : nullptr;
       bias_off += 3 * C;
-      RC(linear_fwd(c, xt, M, C, P[ix.qw].warena_off, 3 * C, q.qkv, 3 * C, c.dt, qkvb));
-      klab_swin_attn_args a;
-      memset(&a, 0, sizeof(a));
-      a.dtype = c.dt; a.qkv = q.qkv; a.ctx = q.ctx; a.bias = q.bias; a.logit_scale = W[ix.ls]; a.lse = q.lse;
-      a.B = B; a.R = q.R; a.w = q.w; a.shift = q.shift; a.H = q.H; a.C = C;
-      RC(klab_swin_attn_fwd(&a, c.ws()));
+      static const bool fused_qkv = [] { const char* v = getenv("KLAB_SWIN_FUSED_QKV"); return !v || atoi(v) != 0; }();
+      int qrc = KLAB_ERR_UNSUPPORTED;
+      if (!e->cfg.train_swin && fused_qkv)  // frozen tower, narrow stage: q|k|v never leave the chip
+        qrc = klab_swin_qkv_attn_fused(xt, woff(c, P[ix.qw].warena_off), qkvb, q.ctx, q.bias, W[ix.ls], c.dt, B, q.R, q.w, q.shift, q.H, C,
+                                       c.ws());
+      if (qrc != 0 && qrc != KLAB_ERR_UNSUPPORTED) return qrc;
+      if (qrc != 0) {
+        RC(linear_fwd(c, xt, M, C, P[ix.qw].warena_off, 3 * C, q.qkv, 3 * C, c.dt, qkvb));
+        klab_swin_attn_args a;
+        memset(&a, 0, sizeof(a));
+        a.dtype = c.dt; a.qkv = q.qkv; a.ctx = q.ctx; a.bias = q.bias; a.logit_scale = W[ix.ls]; a.lse = q.lse;
+        a.B = B; a.R = q.R; a.w = q.w; a.shift = q.shift; a.H = q.H; a.C = C;
+        RC(klab_swin_attn_fwd(&a, c.ws()));
+      }
       static const bool fused_proj = [] { const char* v = getenv("KLAB_SWIN_FUSED_PROJ"); return !v || atoi(v) != 0; }();
       int prc = KLAB_ERR_UNSUPPORTED;
       if (!e->cfg.train_swin && fused_proj)  // frozen tower, narrow stage: output projection + LayerNorm + residual in one kernel
@@ -1102,7 +1111,7 @@ int run_graphed(klab_engine* e, int slot, hipStream_t s, F body) {
 int forward_part_a(klab_engine* e, hipStream_t stream, float p, bool refresh_frozen, bool trainable_current) {
   Ctx c{e, stream, e->cfg.dtype, e->es};
   const klab_model_cfg& cfg = e->cfg;
-  const float* pixels = e->pixels_buf;
+  const float* pixels = e->pixels_cur;
   const long long *src_ids = e->src_buf, *tgt_ids = e->tgt_buf;
   hipLaunchKernelGGL(seed_step_kernel, dim3(1), dim3(1), 0, c.s, e->seed_dev);
   // 1. weights: fp32 masters -> compute-dtype arena (+ fused f32 bias vectors)
@@ -1174,8 +1183,13 @@ extern "C" int klab_engine_forward(klab_engine* e, const float* pixels, const lo
   e->last_tgt = e->tgt_buf;
   // stage the inputs (device-to-device, stream-ordered): replayed graphs read fixed addresses
   const int B = e->B, d = cfg.main.d_model;
-  RC((int)hipMemcpyAsync(e->pixels_buf, pixels, (size_t)B * cfg.swin.in_ch * cfg.swin.image_size * cfg.swin.image_size * 4,
-                         hipMemcpyDeviceToDevice, c.s));
+  if (e->use_graph) {  // replayed graphs read fixed addresses; eager launches read the caller's tensor in place (only im2col does)
+    RC((int)hipMemcpyAsync(e->pixels_buf, pixels, (size_t)B * cfg.swin.in_ch * cfg.swin.image_size * cfg.swin.image_size * 4,
+                           hipMemcpyDeviceToDevice, c.s));
+    e->pixels_cur = e->pixels_buf;
+  } else {
+    e->pixels_cur = pixels;
+  }
   RC((int)hipMemcpyAsync(e->src_buf, src_ids, (size_t)B * e->Ls * 8, hipMemcpyDeviceToDevice, c.s));
   RC((int)hipMemcpyAsync(e->tgt_buf, tgt_ids, (size_t)B * e->Lt * 8, hipMemcpyDeviceToDevice, c.s));
   if (!e->seed_set || seed != e->seed_base) {  // (re)seed the device-side counter RNG; each forward then advances it itself

@@ -67,6 +67,13 @@ def layernorm_fwd(y, gamma, beta, shortcut=None, out=None, outt=None, mean=None,
                                    L.stream_ptr()), "klab_layernorm_fwd")
 
 
+def swin_qkv_attn_fused(x, wqkv, bqkv, ctx, bias, logit_scale, *, B, R, w, shift, H, C):
+    """ctx = window attention of (x @ wqkv.T + bqkv) without materialising q|k|v (frozen Swin-V2, HF/swinv2:389-455)."""
+    lib = L.load()
+    L.check(lib.klab_swin_qkv_attn_fused(x.data_ptr(), wqkv.data_ptr(), L.ptr(bqkv), ctx.data_ptr(), bias.data_ptr(), logit_scale.data_ptr(),
+                                         L.dtype_code(x.dtype), B, R, w, shift, H, C, L.stream_ptr()), "klab_swin_qkv_attn_fused")
+
+
 def swin_proj_ln_fused(x, shortcut, w, b, gamma, beta, out, outt=None, eps=1e-5):
     """out = shortcut + LN(x @ w.T + b)*gamma+beta (frozen Swin-V2 attention-output half, C in {64,128})."""
     lib = L.load()

@@ -511,3 +511,27 @@ def test_swin_proj_ln_fused_matches_torch(ops, M, Cc):
     ops.swin_proj_ln_fused(dev(x), dev(sc), dev(w), dev(b), dev(gm), dev(bt), out, outt, eps=1e-5)
     assert rel_l2(out.cpu(), ref) < 1e-3
     assert rel_l2(outt.float().cpu(), ref) < 6e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,Cc,Hh,shift", [(14, 64, 2, 0), (14, 64, 2, 3), (14, 128, 4, 3), (7, 128, 4, 0)])
+def test_swin_qkv_attn_fused_matches_two_kernel_path(ops, R, Cc, Hh, shift):
+    """Frozen-tower fusion == klab_gemm (q|k|v projection) followed by klab_swin_attn_fwd on the same inputs (which the oracle
+    pins, test_swin_attn_*): the only difference is that q|k|v are not rounded to bf16 before the cosine normalisation."""
+    B, w = 3, 7
+    n = w * w
+    g = torch.Generator().manual_seed(9)
+    M = B * R * R
+    x = torch.randn(M, Cc, generator=g).to(torch.bfloat16)
+    wq = (torch.randn(3 * Cc, Cc, generator=g) / Cc ** 0.5).to(torch.bfloat16)
+    bq = torch.randn(3 * Cc, generator=g) * 0.2
+    bq[Cc:2 * Cc] = 0
+    bias = torch.randn(Hh, n, n, generator=g)
+    ls = torch.full((Hh,), 2.0)
+    qkv = torch.empty(M, 3 * Cc, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(dev(x), dev(wq), qkv, M=M, N=3 * Cc, K=Cc, bias=dev(bq))
+    ref = torch.empty(M, Cc, device="cuda", dtype=torch.bfloat16)
+    ops.swin_attn_fwd(qkv, ref, dev(bias), dev(ls), None, B=B, R=R, w=w, shift=shift, H=Hh, C=Cc)
+    out = torch.empty(M, Cc, device="cuda", dtype=torch.bfloat16)
+    ops.swin_qkv_attn_fused(dev(x), dev(wq), dev(bq), out, dev(bias), dev(ls), B=B, R=R, w=w, shift=shift, H=Hh, C=Cc)
+    assert rel_l2(out.float().cpu(), ref.float().cpu()) < 1.5e-2
