@@ -330,13 +330,21 @@ __global__ __launch_bounds__(64) void swin_qkv_attn_fused(SwinQkvP p) {
   }
   __syncthreads();
   bf16x8 qh[4];  // Q-hat of the 4 query tiles, kappa feature order
+  auto load_x = [&](int mt, bf16x8 (&xf)[KB]) {
+    const int j0 = mt * 16 + lr;
+    const int t = tok[j0 < n ? j0 : n - 1];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) xf[kb] = *reinterpret_cast<const bf16x8*>(p.x + (long)t * C + kb * 32 + g * 8);
+  };
+  bf16x8 xnext[KB];
+  load_x(0, xnext);
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     const int j0 = mt * 16 + lr;                       // window slot of this lane's token
-    const int t = tok[j0 < n ? j0 : n - 1];
     bf16x8 xf[KB];
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) xf[kb] = *reinterpret_cast<const bf16x8*>(p.x + (long)t * C + kb * 32 + g * 8);
+    for (int kb = 0; kb < KB; ++kb) xf[kb] = xnext[kb];
+    if (mt + 1 < 4) load_x(mt + 1, xnext);             // the next tile's rows are in flight during this tile's MFMAs
     f32x4 d[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
