@@ -64,6 +64,9 @@ typedef struct klab_gemm_args {
                     float atomics (summation order, hence the last bits, then vary run to run) */
 } klab_gemm_args;
 int klab_gemm(const klab_gemm_args* args, void* stream);
+/* n independent GEMMs.  Split-K weight-gradient members (bf16, both operands m-major, f32 C with accumulate + atomic_ok, no
+ * epilogue extras) are batched into single launches of up to 8; every other member is run through klab_gemm. */
+int klab_gemm_grouped(const klab_gemm_args* list, int n, void* stream);
 
 /* ---- T5 RMS-norm (T5LayerNorm, HF/t5:59-72) ------------------------------------------------
  * y = drop(x * rsqrt(mean(x^2)+eps) * w); x is the f32 residual stream [rows,d]; y (dtype y_dtype)

@@ -58,6 +58,7 @@ SIGNATURES = {
     "klab_t5_attn_bwd": [C.POINTER(AttnArgs), vp],
     "klab_dbias_reduce": [vp, i32, vp, i32, i32, i32, i32, vp],
     "klab_swin_mlp_fused": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
+    "klab_gemm_grouped": [vp, i32, vp],
     "klab_swin_qkv_attn_fused": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "klab_swin_proj_ln_fused": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
     "klab_swin_attn_fwd": [C.POINTER(SwinAttnArgs), vp],

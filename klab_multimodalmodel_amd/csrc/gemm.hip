@@ -493,7 +493,7 @@ struct GldsOperand {
 // t+1 (other register set) and the LDS-DMA of t+S-1 slotted into the gaps between them.  Before this rewrite the
 // three phases ran back to back in each wave (measured additive: DMA issue + LDS latency + MFMA).
 template <int BM, int BN, bool AK, bool BKM, bool ATOMIC>
-__device__ __forceinline__ void gemm_glds_body(const GemmP& p) {
+__device__ __forceinline__ void gemm_glds_body(const GemmP& p, const int bid = blockIdx.x) {
   typedef bf16_t T;
   constexpr int BK = 32, S = KLAB_GLDS_STAGES;
   static_assert(S == 4, "the steady-state loop is unrolled over a 4-stage ring");
@@ -510,7 +510,7 @@ __device__ __forceinline__ void gemm_glds_body(const GemmP& p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = (wave >> 1) * WTM, wn = (wave & 1) * WTN;
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  const int tile = blockIdx.x % tiles, split = blockIdx.x / tiles;
+  const int tile = bid % tiles, split = bid / tiles;
   int bm0, bn0;
   tile_of_block(p, BM, BN, tile, bm0, bn0);
   const int nt_all = p.K / BK;
@@ -674,6 +674,27 @@ __device__ __forceinline__ void gemm_glds_body(const GemmP& p) {
 }
 template <int BM, int BN, bool AK, bool BKM, bool ATOMIC>
 __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmP p) { gemm_glds_body<BM, BN, AK, BKM, ATOMIC>(p); }
+
+// Grouped launch: up to 8 independent split-K weight-gradient GEMMs (both operands m-major, f32 atomic accumulation) in ONE
+// grid.  A layer's 4-7 weight gradients are 2-9 GFLOP each: launched one by one on the side stream each of them under-fills
+// the chip and pays its own launch; together they are one ~30 GFLOP kernel whose small members fill the big ones' tails.
+struct GroupEntry { const void* A; long lda; const void* B; long ldb; float* C; long ldc; int M, N, K, splits, start; float alpha; };
+struct GroupP { GroupEntry e[8]; int n; };
+__global__ __launch_bounds__(256) void gemm_glds_grouped_tn_kernel(GroupP g) {
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < 8; ++i)
+    if (i < g.n && (int)blockIdx.x >= g.e[i].start) k = i;
+  const GroupEntry& e = g.e[k];
+  GemmP p;
+  p.M = e.M; p.N = e.N; p.K = e.K;
+  p.A = e.A; p.lda = e.lda; p.a_kmajor = 0; p.B = e.B; p.ldb = e.ldb; p.b_kmajor = 0;
+  p.C = e.C; p.ldc = e.ldc; p.c_f32 = 1; p.accumulate = 1;
+  p.alpha = e.alpha; p.alpha_dev = nullptr; p.bias = nullptr; p.act = 0;
+  p.aux = nullptr; p.ldaux = 0; p.aux_mode = 0; p.aux_scale = 1.f; p.residual = nullptr; p.ldr = 0; p.r_f32 = 1;
+  p.drop_p = 0.f; p.seed = nullptr; p.tag = 0; p.splits = e.splits; p.epi = 0; p.ablate = 0;
+  gemm_glds_body<128, 64, false, false, true>(p, (int)blockIdx.x - e.start);
+}
 
 // One workgroup = 4 waves (2x2) computing a BM x BN tile over k-tiles [kt0, kt1).
 // ATOMIC: split-K partial sums are added to a pre-zeroed / accumulating f32 C with float atomics; the
@@ -891,6 +912,60 @@ static int dispatch_tile(GemmP& p, bool atomic_ok, hipStream_t s) {
 }
 
 }  // namespace klab
+
+// klab_gemm_grouped: see include/klab_mm.h.  Members that do not fit the grouped kernel's form are launched one by one.
+extern "C" int klab_gemm(const klab_gemm_args* a, void* stream);
+extern "C" int klab_gemm_grouped(const klab_gemm_args* list, int n, void* stream) {
+  using namespace klab;
+  if (!list || n < 0) return KLAB_ERR_BADARG;
+  static const bool grouped_on = [] { const char* e = getenv("KLAB_GEMM_GROUPED"); return !e || atoi(e) != 0; }();
+  GroupP g;
+  g.n = 0;
+  int blocks = 0;
+  auto flush = [&]() -> int {
+    if (!g.n) return KLAB_OK;
+    const size_t lds = (size_t)KLAB_GLDS_STAGES * (128 + 64) * 64;
+    const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(gemm_glds_grouped_tn_kernel), lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gemm_glds_grouped_tn_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, g);
+    KLAB_LAUNCH_CHECK();
+    g.n = 0; blocks = 0;
+    return KLAB_OK;
+  };
+  auto fits = [&](const klab_gemm_args* a) {
+    return grouped_on && a->dtype == KLAB_BF16 && !a->a_kmajor && !a->b_kmajor && a->c_dtype == KLAB_F32 && a->accumulate && a->atomic_ok &&
+           !a->bias && !a->act && !a->aux && !a->residual && a->drop_p == 0.f && !a->alpha_dev && a->name_tag == 0 && a->M >= 128 &&
+           a->N >= 64 && (a->K % 32) == 0 && a->K >= 512 && !(a->M & 7) && !(a->N & 7) && !(a->lda & 7) && !(a->ldb & 7) &&
+           !((uintptr_t)a->A & 15) && !((uintptr_t)a->B & 15) && !((uintptr_t)a->C & 15);
+  };
+  // every workgroup of the group gets about the same number of k-tiles: total work / ~4 workgroups per CU, >= 16 k-tiles
+  long work = 0;
+  for (int i = 0; i < n; ++i)
+    if (fits(&list[i])) work += (long)((list[i].M + 127) / 128) * ((list[i].N + 63) / 64) * (list[i].K / 32);
+  static const int tgt = [] { const char* e = getenv("KLAB_GEMM_GROUP_TARGET"); return e ? atoi(e) : 1024; }();
+  long per_wg = work / tgt;
+  if (per_wg < 16) per_wg = 16;
+  for (int i = 0; i < n; ++i) {
+    const klab_gemm_args* a = &list[i];
+    if (!fits(a)) {
+      const int rc = klab_gemm(a, stream);
+      if (rc) return rc;
+      continue;
+    }
+    const long t = (long)((a->M + 127) / 128) * ((a->N + 63) / 64);
+    const int nt = a->K / 32;
+    long sp = (nt + per_wg / 2) / per_wg;
+    if (sp > nt / 16) sp = nt / 16;
+    if (sp > 16) sp = 16;
+    if (sp < 1) sp = 1;
+    GroupEntry& e = g.e[g.n];
+    e.A = a->A; e.lda = a->lda; e.B = a->B; e.ldb = a->ldb; e.C = (float*)a->C; e.ldc = a->ldc;
+    e.M = a->M; e.N = a->N; e.K = a->K; e.splits = (int)sp; e.start = blocks; e.alpha = a->alpha;
+    blocks += (int)(t * sp);
+    if (++g.n == 8) { const int rc = flush(); if (rc) return rc; }
+  }
+  return flush();
+}
 
 extern "C" int klab_gemm(const klab_gemm_args* a, void* stream) {
   using namespace klab;
