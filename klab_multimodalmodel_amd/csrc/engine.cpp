@@ -628,7 +628,14 @@ struct WgradQueue {
     if (q.empty()) return 0;
     RC(side_after_main(c));
     Ctx cs{c.e, c.e->side, c.dt, c.es};
-    for (const PendingWgrad& w : q) RC(linear_wgrad(cs, w.dy, w.lddy, w.x, w.ldx, w.M, w.N, w.K, w.dw));
+    std::vector<klab_gemm_args> gs;  // one grouped launch for the layer's weight gradients
+    gs.reserve(q.size());
+    for (const PendingWgrad& w : q) {
+      klab_gemm_args g = G0(cs, w.N, w.K, w.M, w.dy, w.lddy, 0, w.x, w.ldx, 0, w.dw, w.K, KLAB_F32);  // as linear_wgrad
+      g.accumulate = 1; g.atomic_ok = 1;
+      gs.push_back(g);
+    }
+    RC(klab_gemm_grouped(gs.data(), (int)gs.size(), cs.ws()));
     q.clear();
     return 0;
   }
