@@ -680,6 +680,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmP p) { gemm_glds_bod
 // the chip and pays its own launch; together they are one ~30 GFLOP kernel whose small members fill the big ones' tails.
 struct GroupEntry { const void* A; long lda; const void* B; long ldb; float* C; long ldc; int M, N, K, splits, start; float alpha; };
 struct GroupP { GroupEntry e[8]; int n; };
+template <int BN>
 __global__ __launch_bounds__(256) void gemm_glds_grouped_tn_kernel(GroupP g) {
   int k = 0;
 #pragma unroll
@@ -693,7 +694,7 @@ __global__ __launch_bounds__(256) void gemm_glds_grouped_tn_kernel(GroupP g) {
   p.alpha = e.alpha; p.alpha_dev = nullptr; p.bias = nullptr; p.act = 0;
   p.aux = nullptr; p.ldaux = 0; p.aux_mode = 0; p.aux_scale = 1.f; p.residual = nullptr; p.ldr = 0; p.r_f32 = 1;
   p.drop_p = 0.f; p.seed = nullptr; p.tag = 0; p.splits = e.splits; p.epi = 0; p.ablate = 0;
-  gemm_glds_body<128, 64, false, false, true>(p, (int)blockIdx.x - e.start);
+  gemm_glds_body<128, BN, false, false, true>(p, (int)blockIdx.x - e.start);
 }
 
 // One workgroup = 4 waves (2x2) computing a BM x BN tile over k-tiles [kt0, kt1).
@@ -922,28 +923,36 @@ extern "C" int klab_gemm_grouped(const klab_gemm_args* list, int n, void* stream
   GroupP g;
   g.n = 0;
   int blocks = 0;
-  auto flush = [&]() -> int {
-    if (!g.n) return KLAB_OK;
-    const size_t lds = (size_t)KLAB_GLDS_STAGES * (128 + 64) * 64;
-    const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(gemm_glds_grouped_tn_kernel), lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL(gemm_glds_grouped_tn_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, g);
-    KLAB_LAUNCH_CHECK();
-    g.n = 0; blocks = 0;
-    return KLAB_OK;
-  };
   auto fits = [&](const klab_gemm_args* a) {
     return grouped_on && a->dtype == KLAB_BF16 && !a->a_kmajor && !a->b_kmajor && a->c_dtype == KLAB_F32 && a->accumulate && a->atomic_ok &&
            !a->bias && !a->act && !a->aux && !a->residual && a->drop_p == 0.f && !a->alpha_dev && a->name_tag == 0 && a->M >= 128 &&
            a->N >= 64 && (a->K % 32) == 0 && a->K >= 512 && !(a->M & 7) && !(a->N & 7) && !(a->lda & 7) && !(a->ldb & 7) &&
            !((uintptr_t)a->A & 15) && !((uintptr_t)a->B & 15) && !((uintptr_t)a->C & 15);
   };
+  // 128x128 tiles when every member is at least 128 wide (less operand traffic per flop), else 128x64
+  static const int wide_on = [] { const char* e = getenv("KLAB_GEMM_GROUP_WIDE"); return e ? atoi(e) : 1; }();
+  bool wide = wide_on != 0;
+  for (int i = 0; i < n; ++i)
+    if (fits(&list[i]) && list[i].N < 128) wide = false;
+  const int BNr = wide ? 128 : 64;
+  auto flush = [&]() -> int {
+    if (!g.n) return KLAB_OK;
+    const size_t lds = (size_t)KLAB_GLDS_STAGES * (128 + BNr) * 64;
+    int rc = ensure_dyn_lds(wide ? reinterpret_cast<const void*>(gemm_glds_grouped_tn_kernel<128>)
+                                 : reinterpret_cast<const void*>(gemm_glds_grouped_tn_kernel<64>), lds);
+    if (rc) return rc;
+    if (wide) hipLaunchKernelGGL(gemm_glds_grouped_tn_kernel<128>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(gemm_glds_grouped_tn_kernel<64>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, g);
+    KLAB_LAUNCH_CHECK();
+    g.n = 0; blocks = 0;
+    return KLAB_OK;
+  };
   // every workgroup of the group gets about the same number of k-tiles: total work / ~4 workgroups per CU, >= 16 k-tiles
   long work = 0;
   for (int i = 0; i < n; ++i)
-    if (fits(&list[i])) work += (long)((list[i].M + 127) / 128) * ((list[i].N + 63) / 64) * (list[i].K / 32);
+    if (fits(&list[i])) work += (long)((list[i].M + 127) / 128) * ((list[i].N + BNr - 1) / BNr) * (list[i].K / 32);
   static const int tgt = [] { const char* e = getenv("KLAB_GEMM_GROUP_TARGET"); return e ? atoi(e) : 1024; }();
-  long per_wg = work / tgt;
+  long per_wg = work / (wide ? tgt / 2 : tgt);
   if (per_wg < 16) per_wg = 16;
   for (int i = 0; i < n; ++i) {
     const klab_gemm_args* a = &list[i];
@@ -952,7 +961,7 @@ extern "C" int klab_gemm_grouped(const klab_gemm_args* list, int n, void* stream
       if (rc) return rc;
       continue;
     }
-    const long t = (long)((a->M + 127) / 128) * ((a->N + 63) / 64);
+    const long t = (long)((a->M + 127) / 128) * ((a->N + BNr - 1) / BNr);
     const int nt = a->K / 32;
     long sp = (nt + per_wg / 2) / per_wg;
     if (sp > nt / 16) sp = nt / 16;
