@@ -174,7 +174,7 @@ def test_full_size_architecture_matches_oracle(dtype, loss_tol, cos_min):
     assert c > cos_min
 
 
-def _train_steps(wrap, accumulate=1, steps=3):
+def _train_steps(wrap, accumulate=1, steps=3, fused_adam=False):
     """the reference's loop body (ref/train.py:58-71) on a tiny config; returns losses and final weights."""
     import torch.distributed as dist
     m, g = build("tiny_b", torch.float32, True)
@@ -188,7 +188,11 @@ def _train_steps(wrap, accumulate=1, steps=3):
         core = model.module
     else:
         model = core = m
-    opt = torch.optim.Adam(core.transformer.parameters(), lr=1e-3)
+    if fused_adam:
+        from klab_multimodalmodel_amd.optim import FusedAdam
+        opt = FusedAdam(core.transformer.parameters(), lr=1e-3)
+    else:
+        opt = torch.optim.Adam(core.transformer.parameters(), lr=1e-3)
     losses = []
     for i in range(steps * accumulate):
         loss = run(model, g) if wrap else run(m, g)
@@ -215,6 +219,10 @@ def test_reference_training_loop_under_stock_ddp_and_klab_ddp():
             l0, w0, s0 = _train_steps(None, acc)
             l1, w1, s1 = _train_steps("torch", acc)
             l2, w2, s2 = _train_steps("klab", acc)
+            l3, w3, _s3 = _train_steps("klab", acc, fused_adam=True)  # klab DDP + klab FusedAdam (what bench.py runs at N > 1)
+            assert max(abs(x - y) for x, y in zip(l0, l3)) < 2e-4, (acc, l0, l3)
+            for k in w0:
+                assert rel_l2(w3[k].cpu(), w0[k].cpu()) < 2e-3, k
             assert l0[0] > l0[-1]  # it learns the batch
             for a, b in ((l0, l1), (l0, l2)):
                 assert max(abs(x - y) for x, y in zip(a, b)) < 2e-4, (acc, a, b)
