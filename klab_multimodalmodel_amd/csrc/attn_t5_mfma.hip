@@ -207,6 +207,21 @@ __global__ __launch_bounds__(256) void t5_attn_bwd_mfma(AttnMP p) {
   const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
 
+  // position-bias values of each wave's FIRST tile pair in both phases: requested before anything else, so that they
+  // arrive under the staging pass instead of as a separate global round trip in front of each phase
+  f32x4 preA[2], preB[2];
+  {
+    const int qa = wave * 16 + (lane & 15), kb_ = wave * 16 + (lane & 15);
+    const float* browa = (p.bias && qa < Lq) ? p.bias + ((long)h * Lq + qa) * Lk : nullptr;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = u * 16 + g * 4 + r, qq = u * 16 + g * 4 + r;
+        preA[u][r] = browa ? browa[key < Lk ? key : Lk - 1] : 0.f;
+        preB[u][r] = p.bias ? p.bias[((long)h * Lq + (qq < Lq ? qq : Lq - 1)) * Lk + (kb_ < Lk ? kb_ : Lk - 1)] : 0.f;
+      }
+  }
   bool staged_delta = false;  // the fast staging path below also produces delta / lse (no second round of loads)
   {
     // all global loads of the four operand slices go out before the first LDS store (one memory round trip instead of
@@ -314,7 +329,8 @@ __global__ __launch_bounds__(256) void t5_attn_bwd_mfma(AttnMP p) {
         }
     };
     f32x4 bcur[2], bnxt[2];
-    load_bias_a(0, bcur);
+    if (qt == wave) { bcur[0] = preA[0]; bcur[1] = preA[1]; }
+    else load_bias_a(0, bcur);
     for (int sidx = 0; sidx < NK / 2; ++sidx) {
       if (sidx + 1 < NK / 2) load_bias_a(sidx + 1, bnxt);
       f32x4 ds2[2];
@@ -378,7 +394,8 @@ __global__ __launch_bounds__(256) void t5_attn_bwd_mfma(AttnMP p) {
         }
     };
     f32x4 bcur[2], bnxt[2];
-    load_bias_b(0, bcur);
+    if (kt == wave) { bcur[0] = preB[0]; bcur[1] = preB[1]; }
+    else load_bias_b(0, bcur);
     for (int sidx = 0; sidx < NQ / 2; ++sidx) {
       if (sidx + 1 < NQ / 2) load_bias_b(sidx + 1, bnxt);
       f32x4 pd2[2], ds2[2];
