@@ -1115,7 +1115,7 @@ int run_graphed(klab_engine* e, int slot, hipStream_t s, F body) {
 }
 
 // everything of the forward before the LM head (inputs are the engine-owned staged copies)
-int forward_part_a(klab_engine* e, hipStream_t stream, float p, bool refresh_frozen, bool trainable_current) {
+int forward_part_a(klab_engine* e, hipStream_t stream, float p, bool refresh_frozen, bool trainable_current, bool encoder_current = false) {
   Ctx c{e, stream, e->cfg.dtype, e->es};
   const klab_model_cfg& cfg = e->cfg;
   const float* pixels = e->pixels_cur;
@@ -1133,6 +1133,7 @@ int forward_part_a(klab_engine* e, hipStream_t stream, float p, bool refresh_fro
   //    enqueued FIRST on the main stream -- its launches are long, so the host runs far ahead -- and the frozen
   //    language encoder (model.py:20-21, rows [N_img, Le); ~100 launches of ~5 us over 576 tokens, which would
   //    otherwise be paced by the host) is then enqueued on the side stream and runs underneath it.
+  if (!encoder_current) {  // (greedy decoding re-enters with the same images / prompt: encoder output and cross K/V stay valid)
   RC((int)hipEventRecord(e->ev_fork, c.s));
   RC(swin_forward(c, pixels, p, refresh_frozen || e->cfg.train_swin));
   RC((int)hipStreamWaitEvent(e->side, e->ev_fork, 0));
@@ -1148,11 +1149,13 @@ int forward_part_a(klab_engine* e, hipStream_t stream, float p, bool refresh_fro
   // 4. T5 encoder (HF/t5:1009-1016)
   RC(t5_stack_forward(c, cfg.main, e->P[2], e->W[2], e->mi.enc, e->mi.enc_final, e->enc, false, STACK_ENC, p, B, nullptr, 0, 0, nullptr, 0, 0, 0,
                       p));
+  }
   // 5. decoder: shift_right + embedding (HF/t5:1026-1028), cross K/V of all layers in one GEMM, stack
   const int inner = cfg.main.n_heads * cfg.main.d_kv, nld = cfg.main.n_dec_layers;
   RC(klab_embed_fwd(tgt_ids, 1, e->Lt, cfg.main.start_id, cfg.main.pad_id, e->W[2][e->mi.shared], cfg.main.vocab, e->dec.h[0], B * e->Lt, d, p,
                     e->seed_dev, tag_of(STACK_DEC, 0, SITE_IN), e->err_dev, c.ws()));
-  RC(linear_fwd(c, e->enc.out_t, B * e->Le, d, e->kvall_w_off, nld * 2 * inner, e->kv_all, (long)nld * 2 * inner, c.dt));
+  if (!encoder_current)
+    RC(linear_fwd(c, e->enc.out_t, B * e->Le, d, e->kvall_w_off, nld * 2 * inner, e->kv_all, (long)nld * 2 * inner, c.dt));
   RC(t5_stack_forward(c, cfg.main, e->P[2], e->W[2], e->mi.dec, e->mi.dec_final, e->dec, true, STACK_DEC, p, B, e->kv_all, e->Le,
                       (long)nld * 2 * inner, nullptr, 0, 0, 0, p));
   return 0;
@@ -1206,9 +1209,14 @@ extern "C" int klab_engine_forward(klab_engine* e, const float* pixels, const lo
   // bit 2: the optimizer step (klab_engine_adam_step) already refreshed the trainable weights' compute-dtype copies.
   // Ignored under graph replay, whose captured sequence always contains the cast.
   const bool tcur = (training & 4) && !e->use_graph;
+  // bit 3: same images, prompt and weights as the previous forward of this binding, evaluation mode: only the decoder and the
+  // LM head run (greedy decoding, ref/models/model.py:28).  Ignored under graph replay and whenever gradients are wanted.
+  const bool ecur = (training & 8) && !(training & 1) && !want_grad && !e->use_graph && e->frozen_valid && !refresh_frozen;
   if (refresh_frozen) {  // not worth a graph slot: happens once per weight version
     RC(forward_part_a(e, c.s, p, true, tcur));
     e->frozen_valid = true;
+  } else if (ecur) {
+    RC(forward_part_a(e, c.s, p, false, true, true));
   } else {
     RC(run_graphed(e, (training & 1) ? 1 : 0, c.s, [&]() { return forward_part_a(e, c.s, p, false, tcur); }));
   }

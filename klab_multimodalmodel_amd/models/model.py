@@ -342,7 +342,8 @@ class MyModel(nn.Module):
     @torch.no_grad()
     def generate(self, pixels, src, max_length=20):
         """greedy decoding with HF's default generation settings (ref/models/model.py:28: max_length 20,
-        no sampling): re-runs the engine forward per step (no KV cache yet)."""
+        no sampling).  Swin, both encoders and the cross K/V run once; every further step re-runs only the decoder
+        stack and the LM head over the prefix (no per-token KV cache yet)."""
         B = src.shape[0]
         cfg = self.main_cfg
         steps = max_length - 1
@@ -353,7 +354,7 @@ class MyModel(nn.Module):
         try:
             for t in range(steps):
                 eng = self._engine_for(pixels, src, tgt)
-                eng.forward(pixels, src, tgt, training=False, seed=self._seed_base, want_grad=False)
+                eng.forward(pixels, src, tgt, training=(8 if t > 0 else 0) | (2 if t > 0 else 0), seed=self._seed_base, want_grad=False)
                 logits = eng.buffer("logits").view(B, steps, -1)[:, t].float()
                 nxt = logits.argmax(-1)
                 nxt = torch.where(done, torch.full_like(nxt, cfg.pad_token_id), nxt)
