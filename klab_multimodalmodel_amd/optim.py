@@ -118,9 +118,13 @@ class FusedAdam(Optimizer):
         return super().state_dict()
 
     def load_state_dict(self, state_dict):
+        """torch.optim.Adam-compatible.  The model must have been bound to a batch shape (one forward) so that the flat state
+        layout is known; otherwise the loaded state is kept per parameter and the torch fallback continues from it."""
         super().load_state_dict(state_dict)
         model = self._find_owner()
         steps = 0
+        if model is not None and model._flat.get("main") is not None:
+            model._grad_targets()  # builds the parameter -> flat-buffer views if no backward has run yet
         if model is not None and model._views:
             flat = model._flat["main"]
             self._m, self._v = torch.zeros_like(flat), torch.zeros_like(flat)
@@ -133,5 +137,9 @@ class FusedAdam(Optimizer):
                 self._v[off:off + p.numel()].view(p.shape).copy_(st["exp_avg_sq"])
                 steps = max(steps, int(float(st["step"])))
             self._owner = weakref.ref(model)
-        self._steps = steps
-        self._fallback = None
+            self._steps = steps
+            self._fallback = None
+        else:  # no flat layout yet: continue with torch.optim.Adam on the loaded per-parameter state
+            self._fallback = _TorchAdam(self.param_groups)
+            self._fallback.param_groups = self.param_groups
+            self._fallback.state = self.state
