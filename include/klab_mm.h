@@ -146,7 +146,7 @@ typedef struct klab_swin_attn_args {
 int klab_swin_attn_fwd(const klab_swin_attn_args* a, void* stream);
 /* Frozen tower (forward only): the q|k|v projection fused into the window attention, HF/swinv2:389-455 in one kernel.
  * x [B*R*R, C] (the block's LN'd input), wqkv [3C, C] rows q|k|v, bqkv [3C] f32 (k part zero) or NULL, ctx [B*R*R, C].
- * bf16, head dim 32, C in {64, 128}, w*w <= 64; otherwise KLAB_ERR_UNSUPPORTED (caller: klab_gemm + klab_swin_attn_fwd). */
+ * bf16, head dim 32, C in {64, 128, 256}, w*w <= 64; otherwise KLAB_ERR_UNSUPPORTED (caller: klab_gemm + klab_swin_attn_fwd). */
 int klab_swin_qkv_attn_fused(const void* x, const void* wqkv, const float* bqkv, void* ctx, const float* bias, const float* logit_scale,
                              int dtype, int B, int R, int w, int shift, int H, int C, void* stream);
 int klab_swin_attn_bwd(const klab_swin_attn_args* a, void* stream);

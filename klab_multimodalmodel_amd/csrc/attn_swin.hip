@@ -318,41 +318,12 @@ __global__ __launch_bounds__(64) void swin_qkv_attn_fused(SwinQkvP p) {
     }
     tok[lane] = t; reg[lane] = rg;
   }
-  // this head's 96 weight rows as MFMA A fragments (row = lane&15 of the tile, k = 32 kb + 8 g ..): tiles q0 q1 k0 k1 v0 v1
-  bf16x8 wf[6][KB];
-  f32x4 bq[6];
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    const int row = (j >> 1) * C + h * HD + (j & 1) * 16;
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) wf[j][kb] = *reinterpret_cast<const bf16x8*>(p.wqkv + (long)(row + lr) * C + kb * 32 + g * 8);
-    bq[j] = p.bqkv ? *reinterpret_cast<const f32x4*>(p.bqkv + row + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-  }
   __syncthreads();
   bf16x8 qh[4];  // Q-hat of the 4 query tiles, kappa feature order
-  auto load_x = [&](int mt, bf16x8 (&xf)[KB]) {
+  // d[j][r] = feature 16 (j&1) + 4 g + r of q (j = 0,1) / k (2,3) / v (4,5) for the token in window slot mt*16 + lane&15:
+  // L2 norms over the 32 features (in-lane + lane groups), Q-hat to registers, K-hat / V to the LDS images
+  auto finish_tile = [&](int mt, const f32x4 (&d)[6]) {
     const int j0 = mt * 16 + lr;
-    const int t = tok[j0 < n ? j0 : n - 1];
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) xf[kb] = *reinterpret_cast<const bf16x8*>(p.x + (long)t * C + kb * 32 + g * 8);
-  };
-  bf16x8 xnext[KB];
-  load_x(0, xnext);
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int j0 = mt * 16 + lr;                       // window slot of this lane's token
-    bf16x8 xf[KB];
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) xf[kb] = xnext[kb];
-    if (mt + 1 < 4) load_x(mt + 1, xnext);             // the next tile's rows are in flight during this tile's MFMAs
-    f32x4 d[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      d[j] = bq[j];
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb) d[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][kb], xf[kb], d[j], 0, 0, 0);
-    }
-    // d[j][r] = feature 16 (j&1) + 4 g + r of q / k / v for token j0.  L2 norms over the 32 features: in-lane + lane groups
     float sq = 0.f, sk = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { sq += d[0][r] * d[0][r] + d[1][r] * d[1][r]; sk += d[2][r] * d[2][r] + d[3][r] * d[3][r]; }
@@ -371,6 +342,79 @@ __global__ __launch_bounds__(64) void swin_qkv_attn_fused(SwinQkvP p) {
       *reinterpret_cast<bf16x4*>(Kr + j0 * KP + col * 2) = kk;
       *reinterpret_cast<bf16x4*>(Vt + swin_tr_off(j0, col)) = vv;
     }
+  };
+  f32x4 bq[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int row = (j >> 1) * C + h * HD + (j & 1) * 16;
+    bq[j] = p.bqkv ? *reinterpret_cast<const f32x4*>(p.bqkv + row + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if constexpr (C <= 128) {
+    // this head's 96 weight rows as MFMA A fragments (row = lane&15 of the tile, k = 32 kb + 8 g ..), all k blocks in
+    // registers for the 4 token tiles: tiles q0 q1 k0 k1 v0 v1
+    bf16x8 wf[6][KB];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int row = (j >> 1) * C + h * HD + (j & 1) * 16;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) wf[j][kb] = *reinterpret_cast<const bf16x8*>(p.wqkv + (long)(row + lr) * C + kb * 32 + g * 8);
+    }
+    auto load_x = [&](int mt, bf16x8 (&xf)[KB]) {
+      const int j0 = mt * 16 + lr;
+      const int t = tok[j0 < n ? j0 : n - 1];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) xf[kb] = *reinterpret_cast<const bf16x8*>(p.x + (long)t * C + kb * 32 + g * 8);
+    };
+    bf16x8 xnext[KB];
+    load_x(0, xnext);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      bf16x8 xf[KB];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) xf[kb] = xnext[kb];
+      if (mt + 1 < 4) load_x(mt + 1, xnext);             // the next tile's rows are in flight during this tile's MFMAs
+      f32x4 d[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        d[j] = bq[j];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) d[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][kb], xf[kb], d[j], 0, 0, 0);
+      }
+      finish_tile(mt, d);
+    }
+  } else {
+    // wide stage (C = 256): the weights do not fit in registers -- k block by k block, 6 weight + 4 token fragments in
+    // flight one block ahead, all 4 x 6 accumulators live
+    const long trow[4] = {(long)tok[min(lr, n - 1)] * C, (long)tok[min(16 + lr, n - 1)] * C, (long)tok[min(32 + lr, n - 1)] * C,
+                          (long)tok[min(48 + lr, n - 1)] * C};
+    auto load_kb = [&](int kb, bf16x8 (&wf)[6], bf16x8 (&xf)[4]) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+        wf[j] = *reinterpret_cast<const bf16x8*>(p.wqkv + (long)((j >> 1) * C + h * HD + (j & 1) * 16 + lr) * C + kb * 32 + g * 8);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) xf[mt] = *reinterpret_cast<const bf16x8*>(p.x + trow[mt] + kb * 32 + g * 8);
+    };
+    f32x4 d[4][6];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) d[mt][j] = bq[j];
+    bf16x8 wn[6], xn[4];
+    load_kb(0, wn, xn);
+    for (int kb = 0; kb < KB; ++kb) {
+      bf16x8 wc[6], xc[4];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) wc[j] = wn[j];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) xc[mt] = xn[mt];
+      if (kb + 1 < KB) load_kb(kb + 1, wn, xn);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) d[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[j], xc[mt], d[mt][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) finish_tile(mt, d[mt]);
   }
   __syncthreads();
   const float scale = __expf(fminf(p.logit_scale[h], 4.6051701859880914f));
@@ -779,6 +823,7 @@ extern "C" int klab_swin_qkv_attn_fused(const void* x, const void* wqkv, const f
   hipStream_t s = (hipStream_t)stream;
   if (C == 64) hipLaunchKernelGGL(swin_qkv_attn_fused<64>, dim3(B * nW * H), dim3(64), 0, s, p);
   else if (C == 128) hipLaunchKernelGGL(swin_qkv_attn_fused<128>, dim3(B * nW * H), dim3(64), 0, s, p);
+  else if (C == 256) hipLaunchKernelGGL(swin_qkv_attn_fused<256>, dim3(B * nW * H), dim3(64), 0, s, p);
   else return KLAB_ERR_UNSUPPORTED;
   KLAB_LAUNCH_CHECK();
   return KLAB_OK;

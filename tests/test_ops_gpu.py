@@ -514,7 +514,7 @@ def test_swin_proj_ln_fused_matches_torch(ops, M, Cc):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("R,Cc,Hh,shift", [(14, 64, 2, 0), (14, 64, 2, 3), (14, 128, 4, 3), (7, 128, 4, 0)])
+@pytest.mark.parametrize("R,Cc,Hh,shift", [(14, 64, 2, 0), (14, 64, 2, 3), (14, 128, 4, 3), (7, 128, 4, 0), (14, 256, 8, 3), (14, 256, 8, 0)])
 def test_swin_qkv_attn_fused_matches_two_kernel_path(ops, R, Cc, Hh, shift):
     """Frozen-tower fusion == klab_gemm (q|k|v projection) followed by klab_swin_attn_fwd on the same inputs (which the oracle
     pins, test_swin_attn_*): the only difference is that q|k|v are not rounded to bf16 before the cosine normalisation."""
