@@ -391,3 +391,46 @@ def test_checkpoint_resume_with_fused_adam(tmp_path):
     assert o2._fallback is None, o2._fb_reason
     for a, b in zip(ref, first + rest):
         assert abs(a - b) <= 2e-5 * abs(a) + 1e-6, (ref, first + rest)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,loss_tol,cos_min", [(torch.float32, 3e-5, 0.9999), (torch.bfloat16, 3e-3, 0.99)])
+def test_config3_architecture_with_trainable_swin_matches_oracle(dtype, loss_tol, cos_min):
+    """BASELINE configs[2]/[3] architecture as SURVEY §8(d) resolves it -- Swin-V2 C=96 heads (3,6,12,24) 224 w7, UNFROZEN, +
+    T5-base (d=768, 12 heads, ff 3072), V=32128 -- at B=1 with the Swin depth cut to (2,2,2,2) and 3+3 T5 layers so that the
+    CPU oracle finishes in seconds: exercises widths 96/192/384/768 (3-k-tile GEMMs, 24-lane LayerNorm rows, 768-wide
+    RMS-norm), 12-head attention and the Swin backward kernels at n=49."""
+    from klab_multimodalmodel_amd.engine import SwinConfig, T5Config
+    from klab_multimodalmodel_amd.models.model import MyModel
+    sw = SwinConfig(image_size=224, embed_dim=96, depths=(2, 2, 2, 2), num_heads=(3, 6, 12, 24), window_size=7)
+    t5 = T5Config(d_model=768, d_ff=3072, num_heads=12, num_layers=3, num_decoder_layers=3)
+    args = types.SimpleNamespace(result_dir="/tmp", language_model_name="-", image_model_name="-", image_model_train=True,
+                                 transformer_model_name="-")
+    m = MyModel(args, _configs=(sw, t5, t5), _seed=5, dtype=dtype)
+    O, sc, lc, mc, (ssd, lsd, msd) = _oracle_from_model(m)
+    m = m.to("cuda")
+    m.transformer.eval()
+    g = torch.Generator().manual_seed(77)
+    B, Ls, Lt = 1, 9, 32
+    pix = torch.randn(B, 3, 224, 224, generator=g)
+    src = torch.randint(2, 32000, (B, Ls), generator=g)
+    tgt = torch.randint(2, 32000, (B, Lt), generator=g)
+    tgt[0, -5:] = 0
+    loss = m({"pixel_values": pix.cuda()}, {"input_ids": src.cuda()}, {"input_ids": tgt.cuda()})
+    loss.backward()
+    msd = {k: v.requires_grad_(True) for k, v in msd.items()}
+    ssd = {k: (v.requires_grad_(True) if v.is_floating_point() else v) for k, v in ssd.items()}
+    torch.set_num_threads(8)
+    ref = O.mymodel_forward(ssd, lsd, msd, sc, lc, mc, pix, src, tgt, training=False, image_model_train=True)
+    ref.backward()
+    assert abs(loss.item() - float(ref)) <= loss_tol * abs(float(ref)), (loss.item(), float(ref))
+    for tree, sd, name in ((m.transformer, msd, "t5"), (m.image_model, ssd, "swin")):
+        a, b = [], []
+        for k, p in tree.named_parameters():
+            if p.grad is None or sd[k].grad is None:
+                continue
+            a.append(p.grad.cpu().flatten())
+            b.append(sd[k].grad.flatten())
+        c = cosine(torch.cat(a), torch.cat(b))
+        print("cfg3-arch", dtype, name, "grad cosine", c, "rel-L2", rel_l2(torch.cat(a), torch.cat(b)))
+        assert c > cos_min, (name, c)
