@@ -94,6 +94,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise KlabError(f"{LIB_PATH} is missing: run `python -m klab_multimodalmodel_amd.build` "
                         "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # torch first: its wheel bundles its own libamdhip64 -- loaded before ours, our library's HIP symbols bind to that same
+    # runtime instance (loaded after, the process would hold two HIP runtimes and every torch pointer / stream handed to the
+    # C ABI would be foreign to ours: hipErrorNoDevice at klab_engine_bind)
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, argt in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
