@@ -126,6 +126,9 @@ typedef struct klab_attn_args {
   void* ds_ws; /* optional scratch [B,H,Lq,roundup(Lk,32)] in `dtype`: with it the position-bias gradient is a
                   deterministic batch reduction of stored dS instead of 64-way contended float atomics */
   int ds_defer; /* 1: only store dS; the caller reduces several layers' scratch at once with klab_dbias_reduce */
+  /* backward, bf16 MFMA path only (used for the Swin-V2 window attention on window-ordered copies): */
+  const float* score_scale; /* [H] device: S = score_scale[h] * Q K^T + bias (fp32), NULL = 1 */
+  int bias_mod;             /* > 0: bias is [bias_mod, H, Lq, Lk] and batch element b uses slab b % bias_mod */
 } klab_attn_args;
 int klab_t5_attn_fwd(const klab_attn_args* a, void* stream);
 int klab_t5_attn_bwd(const klab_attn_args* a, void* stream);
@@ -136,14 +139,21 @@ int klab_dbias_reduce(const void* ds_ws, int dtype, float* dbias, int nbatch, in
  * :652-705, :146-166, :620-643) -- one call per block.  qkv [B*R*R, 3C], ctx [B*R*R, C] (`dtype`),
  * bias [H, w*w, w*w] f32 (= 16*sigmoid(CPB), klab_swin_cpb_bias), logit_scale [H] f32 (raw param),
  * lse [B*nW*H*w*w] f32 (fwd out, optional; bwd in).  bwd writes dqkv and accumulates dbias /
- * dlogit_scale.  R % w must be 0 (the padded-window path is out of scope).                      */
+ * dlogit_scale.  R % w must be 0 (the padded-window path is out of scope).
+ * bwd_ws / bwd_ws_bytes (optional): scratch of at least klab_swin_attn_bwd_ws_bytes(...) bytes; with it (bf16, head dim 32,
+ * w*w <= 64) the backward runs on the matrix cores -- window-ordered unit q|k|v copies, the T5 attention backward kernel with a
+ * per-head score scale and the per-window bias+mask table, then the L2-normalisation Jacobian on the way back to token
+ * order.  Without it (or outside that envelope) the vector-ALU kernel runs.                       */
 typedef struct klab_swin_attn_args {
   int dtype;
   const void* qkv; void* ctx; const float* bias; const float* logit_scale; float* lse;
   int B, R, w, shift, H, C;
   const void* dctx; void* dqkv; float* dbias; float* dlogit_scale;
+  void* bwd_ws; size_t bwd_ws_bytes;
 } klab_swin_attn_args;
 int klab_swin_attn_fwd(const klab_swin_attn_args* a, void* stream);
+/* scratch bytes the matrix-core backward needs for this shape (0: shape outside its envelope) */
+size_t klab_swin_attn_bwd_ws_bytes(int dtype, int B, int R, int w, int H, int C);
 /* Frozen tower (forward only): the q|k|v projection fused into the window attention, HF/swinv2:389-455 in one kernel.
  * x [B*R*R, C] (the block's LN'd input), wqkv [3C, C] rows q|k|v, bqkv [3C] f32 (k part zero) or NULL, ctx [B*R*R, C].
  * bf16, head dim 32, C in {64, 128, 256}, w*w <= 64; otherwise KLAB_ERR_UNSUPPORTED (caller: klab_gemm + klab_swin_attn_fwd). */

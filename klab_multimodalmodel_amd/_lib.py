@@ -33,13 +33,15 @@ class AttnArgs(C.Structure):
                 ("B", i32), ("H", i32), ("Lq", i32), ("Lk", i32), ("dk", i32),
                 ("drop_p", f32), ("seed_dev", vp), ("drop_tag", u32),
                 ("dctx", vp), ("lddo", i64), ("dq", vp), ("lddq", i64), ("dk_out", vp), ("lddk", i64),
-                ("dv", vp), ("lddv", i64), ("dbias", vp), ("ds_ws", vp), ("ds_defer", i32)]
+                ("dv", vp), ("lddv", i64), ("dbias", vp), ("ds_ws", vp), ("ds_defer", i32),
+                ("score_scale", vp), ("bias_mod", i32)]
 
 
 class SwinAttnArgs(C.Structure):
     _fields_ = [("dtype", i32), ("qkv", vp), ("ctx", vp), ("bias", vp), ("logit_scale", vp), ("lse", vp),
                 ("B", i32), ("R", i32), ("w", i32), ("shift", i32), ("H", i32), ("C", i32),
-                ("dctx", vp), ("dqkv", vp), ("dbias", vp), ("dlogit_scale", vp)]
+                ("dctx", vp), ("dqkv", vp), ("dbias", vp), ("dlogit_scale", vp),
+                ("bwd_ws", vp), ("bwd_ws_bytes", C.c_size_t)]
 
 
 # every exported entry point of include/klab_mm.h: name -> argtypes (restype is always int)
@@ -63,6 +65,7 @@ SIGNATURES = {
     "klab_swin_proj_ln_fused": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
     "klab_swin_attn_fwd": [C.POINTER(SwinAttnArgs), vp],
     "klab_swin_attn_bwd": [C.POINTER(SwinAttnArgs), vp],
+    "klab_swin_attn_bwd_ws_bytes": [i32, i32, i32, i32, i32, i32],
     "klab_swin_cpb_bias": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "klab_cast_pack": [vp, i32, i64, vp, i32, vp],
     "klab_embed_fwd": [vp, i32, i32, i32, i32, vp, i32, vp, i32, i32, f32, vp, u32, vp, vp],
@@ -102,7 +105,7 @@ def load():
     for name, argt in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argt
-        fn.restype = i32
+        fn.restype = C.c_size_t if name.endswith("_ws_bytes") else i32
     _lib = lib
     return lib
 

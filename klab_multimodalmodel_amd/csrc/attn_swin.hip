@@ -12,6 +12,7 @@
 // Round-1 form: fp32 vector-ALU dot products (n = 49, hd = 32 tiles are awkward MFMA shapes; the
 // padded-to-64 MFMA form is the planned replacement, SURVEY §7 "small-tile efficiency").
 #include <math.h>
+#include <string.h>
 
 #include "common.h"
 #include "klab_mm.h"
@@ -711,6 +712,138 @@ __global__ __launch_bounds__(256) void cpb_mlp_bwd_kernel(const float* __restric
   dw0[j * 2] += a0; dw0[j * 2 + 1] += a1; db0[j] += ab;
 }
 
+// ---- matrix-core backward (bf16, head dim 32, windows of <= 64 tokens) -------------------------------------------------------
+// Three passes around t5_attn_bwd_mfma<32> (attn_t5_mfma.hip), which already is the softmax-attention backward on the matrix
+// cores: (1) gather the window's tokens (roll + partition as index math) into window-major unit-q | unit-k | v, dO and O
+// copies and keep 1/|q|, 1/|k|; (2) the T5 kernel with score = scale_h * (q-hat . k-hat) + bias[window] (+ shift mask, folded
+// into a per-window table), P recomputed from the forward's LSE, dS stored for the bias gradient; (3) back to token order
+// through the Jacobian of x / |x| and the logit-scale gradient.  Every pass addresses whole 64-byte head slices with 4 lanes.
+struct SwinBwdWs {
+  size_t g, dow, ow, dg, invn, scale, ds, biasw, total;
+};
+__host__ inline SwinBwdWs swin_bwd_ws(int B, int R, int w, int H, int C) {
+  const size_t M = (size_t)B * R * R, n = (size_t)w * w, nW = (size_t)(R / w) * (R / w);
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  SwinBwdWs o;
+  size_t off = 0;
+  o.g = off; off += al(M * 3 * C * 2);
+  o.dow = off; off += al(M * C * 2);
+  o.ow = off; off += al(M * C * 2);
+  o.dg = off; off += al(M * 3 * C * 2);
+  o.invn = off; off += al(M * H * 2 * 4);
+  o.scale = off; off += al((size_t)H * 4);
+  o.ds = off; off += al((size_t)B * nW * H * n * 64 * 2);
+  o.biasw = off; off += al(nW * H * n * n * 4);
+  o.total = off;
+  return o;
+}
+
+struct SwinBwdP {
+  const bf16_t* qkv; const bf16_t* ctx; const bf16_t* dctx; bf16_t* dqkv;
+  bf16_t* g; bf16_t* dow; bf16_t* ow; const bf16_t* dg; float* invn; float* scale; const float* logit_scale; float* dlogit_scale;
+  int B, R, w, shift, H, C;
+};
+__device__ __forceinline__ int swin_token_of_row(long rw, int n, int nW, int nWr, int w, int R, int shift) {
+  const int j = (int)(rw % n);
+  const int bw = (int)(rw / n);
+  const int win = bw % nW, b = bw / nW;
+  const int ys = (win / nWr) * w + j / w, xs = (win % nWr) * w + j % w;
+  const int y = (ys + shift) % R, x = (xs + shift) % R;
+  return (b * R + y) * R + x;
+}
+
+__global__ __launch_bounds__(256) void swin_bwd_gather_kernel(SwinBwdP p) {
+  const int C = p.C, C8 = C >> 3, n = p.w * p.w, nWr = p.R / p.w, nW = nWr * nWr;
+  const long M = (long)p.B * p.R * p.R;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x == 0 && (int)threadIdx.x < p.H) p.scale[threadIdx.x] = __expf(fminf(p.logit_scale[threadIdx.x], 4.6051701859880914f));
+  if (idx >= M * C8) return;  // C8 is a multiple of 4: the 4 lanes of a head slice leave together
+  const long rw = idx / C8;
+  const int c8 = (int)(idx % C8), h = c8 >> 2;
+  const int t = swin_token_of_row(rw, n, nW, nWr, p.w, p.R, p.shift);
+  const bf16_t* src = p.qkv + (long)t * 3 * C + c8 * 8;
+  bf16x8 q = *reinterpret_cast<const bf16x8*>(src);
+  bf16x8 k = *reinterpret_cast<const bf16x8*>(src + C);
+  const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + 2 * C);
+  const bf16x8 d = *reinterpret_cast<const bf16x8*>(p.dctx + (long)t * C + c8 * 8);
+  const bf16x8 o = *reinterpret_cast<const bf16x8*>(p.ctx + (long)t * C + c8 * 8);
+  float sq = 0.f, sk = 0.f;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) { const float a = (float)q[u], b = (float)k[u]; sq += a * a; sk += b * b; }
+  sq += __shfl_xor(sq, 1, 64); sk += __shfl_xor(sk, 1, 64);
+  sq += __shfl_xor(sq, 2, 64); sk += __shfl_xor(sk, 2, 64);
+  const float iq = 1.f / fmaxf(sqrtf(sq), 1e-12f), ik = 1.f / fmaxf(sqrtf(sk), 1e-12f);  // F.normalize eps (HF/swinv2:413)
+#pragma unroll
+  for (int u = 0; u < 8; ++u) { q[u] = (bf16_t)((float)q[u] * iq); k[u] = (bf16_t)((float)k[u] * ik); }  // same rounding as forward
+  bf16_t* dst = p.g + rw * 3 * C + c8 * 8;
+  *reinterpret_cast<bf16x8*>(dst) = q;
+  *reinterpret_cast<bf16x8*>(dst + C) = k;
+  *reinterpret_cast<bf16x8*>(dst + 2 * C) = v;
+  *reinterpret_cast<bf16x8*>(p.dow + rw * C + c8 * 8) = d;
+  *reinterpret_cast<bf16x8*>(p.ow + rw * C + c8 * 8) = o;
+  if ((c8 & 3) == 0) *reinterpret_cast<float2*>(p.invn + (rw * p.H + h) * 2) = make_float2(iq, ik);
+}
+
+// bias + shift mask per window: biasw[win, h, i, j] = bias[h, i, j] - 200 * (region(i) != region(j))  (HF/swinv2:433-436, twice)
+__global__ __launch_bounds__(256) void swin_bias_mask_kernel(const float* __restrict__ bias, float* __restrict__ biasw, int R, int w, int shift, int H) {
+  const int n = w * w, nWr = R / w, nW = nWr * nWr;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)nW * H * n * n) return;
+  const int j = (int)(idx % n), i = (int)((idx / n) % n);
+  const int h = (int)((idx / ((long)n * n)) % H), win = (int)(idx / ((long)n * n * H));
+  const int wy = win / nWr, wx = win % nWr;
+  const int ri = swin_region(wy * w + i / w, R, w, shift) * 3 + swin_region(wx * w + i % w, R, w, shift);
+  const int rj = swin_region(wy * w + j / w, R, w, shift) * 3 + swin_region(wx * w + j % w, R, w, shift);
+  biasw[idx] = bias[((long)h * n + i) * n + j] + (ri != rj ? -200.f : 0.f);
+}
+
+__global__ __launch_bounds__(256) void swin_bwd_scatter_kernel(SwinBwdP p) {
+  __shared__ float dsc[64];
+  const int C = p.C, C8 = C >> 3, n = p.w * p.w, nWr = p.R / p.w, nW = nWr * nWr, H = p.H;
+  const long M = (long)p.B * p.R * p.R;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (threadIdx.x < 64) dsc[threadIdx.x] = 0.f;
+  __syncthreads();
+  if (idx < M * C8) {
+    const long rw = idx / C8;
+    const int c8 = (int)(idx % C8), h = c8 >> 2;
+    const int t = swin_token_of_row(rw, n, nW, nWr, p.w, p.R, p.shift);
+    const bf16_t* gs = p.g + rw * 3 * C + c8 * 8;
+    const bf16_t* ds = p.dg + rw * 3 * C + c8 * 8;
+    const bf16x8 qh = *reinterpret_cast<const bf16x8*>(gs), kh = *reinterpret_cast<const bf16x8*>(gs + C);
+    const bf16x8 dq = *reinterpret_cast<const bf16x8*>(ds), dk = *reinterpret_cast<const bf16x8*>(ds + C);
+    const bf16x8 dv = *reinterpret_cast<const bf16x8*>(ds + 2 * C);
+    const float2 inv = *reinterpret_cast<const float2*>(p.invn + (rw * H + h) * 2);
+    const float scale = p.scale[h];
+    float dotq = 0.f, dotk = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { dotq += (float)qh[u] * (float)dq[u]; dotk += (float)kh[u] * (float)dk[u]; }
+    dotq += __shfl_xor(dotq, 1, 64); dotk += __shfl_xor(dotk, 1, 64);
+    dotq += __shfl_xor(dotq, 2, 64); dotk += __shfl_xor(dotk, 2, 64);
+    // x-hat = x / |x|:  dx = (dx-hat - x-hat (x-hat . dx-hat)) / |x|, with dx-hat = scale * (kernel's dQ or dK)
+    bf16x8 oq, ok;
+    const float fq = scale * inv.x, fk = scale * inv.y;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      oq[u] = (bf16_t)(((float)dq[u] - (float)qh[u] * dotq) * fq);
+      ok[u] = (bf16_t)(((float)dk[u] - (float)kh[u] * dotk) * fk);
+    }
+    bf16_t* dst = p.dqkv + (long)t * 3 * C + c8 * 8;
+    *reinterpret_cast<bf16x8*>(dst) = oq;
+    *reinterpret_cast<bf16x8*>(dst + C) = ok;
+    *reinterpret_cast<bf16x8*>(dst + 2 * C) = dv;
+    if ((c8 & 3) == 0 && p.dlogit_scale) atomicAdd(&dsc[h & 63], dotq);  // d scale = sum_ij dS_ij (q-hat_i . k-hat_j) = sum_i dQ_i . q-hat_i
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < H && p.dlogit_scale) {
+    const float ls = p.logit_scale[threadIdx.x];
+    if (ls <= 4.6051701859880914f && dsc[threadIdx.x] != 0.f) atomicAdd(p.dlogit_scale + threadIdx.x, dsc[threadIdx.x] * p.scale[threadIdx.x]);
+  }
+}
+
+int t5_attn_bwd_mfma_dispatch(const klab_attn_args* a, hipStream_t s);  // attn_t5_mfma.hip
+int dbias_reduce_dispatch(const void* ds_ws, float* dbias, int nbatch, int H, int Lq, int Lk, hipStream_t s);
+
 }  // namespace klab
 
 using namespace klab;
@@ -766,6 +899,50 @@ extern "C" int klab_swin_attn_fwd(const klab_swin_attn_args* a, void* stream) {
   return KLAB_ERR_UNSUPPORTED;
 }
 
+static bool swin_bwd_mfma_ok(int dtype, int w, int H, int C) { return dtype == KLAB_BF16 && C == H * 32 && w * w <= 64 && H <= 64; }
+
+extern "C" size_t klab_swin_attn_bwd_ws_bytes(int dtype, int B, int R, int w, int H, int C) {
+  if (B <= 0 || R <= 0 || w <= 0 || R % w || !swin_bwd_mfma_ok(dtype, w, H, C)) return 0;
+  return swin_bwd_ws(B, R, w, H, C).total;
+}
+
+static int swin_attn_bwd_mfma(const klab_swin_attn_args* a, hipStream_t s) {
+  const SwinBwdWs L = swin_bwd_ws(a->B, a->R, a->w, a->H, a->C);
+  if (a->bwd_ws_bytes < L.total) return KLAB_ERR_BADARG;
+  char* ws = (char*)a->bwd_ws;
+  const int n = a->w * a->w, nW = (a->R / a->w) * (a->R / a->w), C = a->C, H = a->H;
+  SwinBwdP p{(const bf16_t*)a->qkv, (const bf16_t*)a->ctx, (const bf16_t*)a->dctx, (bf16_t*)a->dqkv,
+             (bf16_t*)(ws + L.g), (bf16_t*)(ws + L.dow), (bf16_t*)(ws + L.ow), (const bf16_t*)(ws + L.dg), (float*)(ws + L.invn),
+             (float*)(ws + L.scale), a->logit_scale, a->dlogit_scale, a->B, a->R, a->w, a->shift, H, C};
+  const long work = (long)a->B * a->R * a->R * (C / 8);
+  const unsigned nb = (unsigned)((work + 255) / 256);
+  hipLaunchKernelGGL(swin_bwd_gather_kernel, dim3(nb), dim3(256), 0, s, p);
+  KLAB_LAUNCH_CHECK();
+  const float* biasw = a->bias;
+  if (a->shift > 0) {
+    const long tot = (long)nW * H * n * n;
+    hipLaunchKernelGGL(swin_bias_mask_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, a->bias, (float*)(ws + L.biasw), a->R, a->w, a->shift, H);
+    KLAB_LAUNCH_CHECK();
+    biasw = (const float*)(ws + L.biasw);
+  }
+  klab_attn_args t;
+  memset(&t, 0, sizeof(t));
+  t.dtype = KLAB_BF16;
+  t.q = ws + L.g; t.k = ws + L.g + (size_t)C * 2; t.v = ws + L.g + (size_t)2 * C * 2; t.ldq = t.ldk = t.ldv = 3L * C;
+  t.bias = biasw; t.bias_mod = a->shift > 0 ? nW : 0; t.score_scale = (const float*)(ws + L.scale);
+  t.ctx = ws + L.ow; t.ldo = C; t.lse = a->lse;
+  t.B = a->B * nW; t.H = H; t.Lq = t.Lk = n; t.dk = 32;
+  t.dctx = ws + L.dow; t.lddo = C;
+  t.dq = ws + L.dg; t.dk_out = ws + L.dg + (size_t)C * 2; t.dv = ws + L.dg + (size_t)2 * C * 2; t.lddq = t.lddk = t.lddv = 3L * C;
+  if (a->dbias) { t.ds_ws = ws + L.ds; t.ds_defer = 1; }
+  int rc = t5_attn_bwd_mfma_dispatch(&t, s);
+  if (rc) return rc;
+  if (a->dbias) { rc = dbias_reduce_dispatch(ws + L.ds, a->dbias, a->B * nW, H, n, n, s); if (rc) return rc; }
+  hipLaunchKernelGGL(swin_bwd_scatter_kernel, dim3(nb), dim3(256), 0, s, p);
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+
 extern "C" int klab_swin_attn_bwd(const klab_swin_attn_args* a, void* stream) {
   int rc = swin_args_ok(a);
   if (rc) return rc;
@@ -774,6 +951,7 @@ extern "C" int klab_swin_attn_bwd(const klab_swin_attn_args* a, void* stream) {
               a->dctx, a->dqkv, a->dbias, a->dlogit_scale};
   const int hd = a->C / a->H;
   hipStream_t s = (hipStream_t)stream;
+  if (a->bwd_ws && swin_bwd_mfma_ok(a->dtype, a->w, a->H, a->C)) return swin_attn_bwd_mfma(a, s);
   if (a->dtype == KLAB_BF16) {
     if (hd == 32) return launch_swin_bwd<bf16_t, 32>(p, s);
     if (hd == 16) return launch_swin_bwd<bf16_t, 16>(p, s);

@@ -277,6 +277,7 @@ extern "C" int klab_t5_attn_fwd(const klab_attn_args* a, void* stream) {
   int rc = check_attn(a);
   if (rc) return rc;
   if (a->B <= 0 || a->Lq <= 0 || a->Lk <= 0) return KLAB_OK;
+  if (a->score_scale || a->bias_mod) return KLAB_ERR_UNSUPPORTED;  // backward-only extensions (Swin window attention)
   if (a->dtype == KLAB_BF16) {  // matrix-core path first; fall through to the generic kernel outside its envelope
     rc = t5_attn_fwd_mfma_dispatch(a, (hipStream_t)stream);
     if (rc != KLAB_ERR_UNSUPPORTED) return rc;
@@ -308,6 +309,7 @@ extern "C" int klab_t5_attn_bwd(const klab_attn_args* a, void* stream) {
     if (rc != KLAB_ERR_UNSUPPORTED) return rc;
   }
   if (a->ds_defer) return KLAB_ERR_UNSUPPORTED;  // only the MFMA kernel stores dS; the caller retries without ds_defer
+  if (a->score_scale || a->bias_mod) return KLAB_ERR_UNSUPPORTED;  // matrix-core kernel only (Swin window attention backward)
   const size_t es = a->dtype == KLAB_BF16 ? 2 : 4;
   const int vec = a->dtype == KLAB_BF16 ? 8 : 4;
   const size_t lds = 2 * (size_t)a->Lk * (a->dk + vec) * es + 2 * (size_t)a->Lk * a->dk * 4 + 2 * (size_t)TQ * a->dk * 4 +

@@ -36,6 +36,8 @@ struct AttnMP {
   float* dbias;
   bf16_t* ds_ws;
   int defer_reduce;
+  const float* score_scale;  // backward only: per-head factor applied to Q K^T in fp32 before the bias (Swin-V2 cosine attention)
+  int bias_mod;              // backward only: > 0 => bias is [bias_mod, H, Lq, Lk], slab (b % bias_mod) (window-dependent shift masks)
 };
 
 template <int COLS> struct TrImg {  // rows = contraction index, columns = COLS 16-bit elements
@@ -207,19 +209,21 @@ __global__ __launch_bounds__(256) void t5_attn_bwd_mfma(AttnMP p) {
   const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
 
+  const float* const biasp = p.bias ? p.bias + (p.bias_mod > 0 ? (long)(b % p.bias_mod) * p.H * Lq * Lk : 0L) : nullptr;
+  const float sscale = p.score_scale ? p.score_scale[h] : 1.f;
   // position-bias values of each wave's FIRST tile pair in both phases: requested before anything else, so that they
   // arrive under the staging pass instead of as a separate global round trip in front of each phase
   f32x4 preA[2], preB[2];
   {
     const int qa = wave * 16 + (lane & 15), kb_ = wave * 16 + (lane & 15);
-    const float* browa = (p.bias && qa < Lq) ? p.bias + ((long)h * Lq + qa) * Lk : nullptr;
+    const float* browa = (biasp && qa < Lq) ? biasp + ((long)h * Lq + qa) * Lk : nullptr;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = u * 16 + g * 4 + r, qq = u * 16 + g * 4 + r;
         preA[u][r] = browa ? browa[key < Lk ? key : Lk - 1] : 0.f;
-        preB[u][r] = p.bias ? p.bias[((long)h * Lq + (qq < Lq ? qq : Lq - 1)) * Lk + (kb_ < Lk ? kb_ : Lk - 1)] : 0.f;
+        preB[u][r] = biasp ? biasp[((long)h * Lq + (qq < Lq ? qq : Lq - 1)) * Lk + (kb_ < Lk ? kb_ : Lk - 1)] : 0.f;
       }
   }
   bool staged_delta = false;  // the fast staging path below also produces delta / lse (no second round of loads)
@@ -309,7 +313,7 @@ __global__ __launch_bounds__(256) void t5_attn_bwd_mfma(AttnMP p) {
   for (int qt = wave; qt < NQ; qt += 4) {
     const int q = qt * 16 + (lane & 15);
     const float lq = lses[q], dq_ = delta[q];
-    const float* brow = (p.bias && q < Lq) ? p.bias + ((long)h * Lq + q) * Lk : nullptr;
+    const float* brow = (biasp && q < Lq) ? biasp + ((long)h * Lq + q) * Lk : nullptr;
     float* dbrow = (p.dbias && !p.ds_ws && q < Lq) ? p.dbias + ((long)h * Lq + q) * Lk : nullptr;
     bf16_t* dsrow = (p.ds_ws && q < Lq) ? p.ds_ws + (((long)b * p.H + h) * Lq + q) * Lkp : nullptr;
     bf16x8 qf[KS], dof[KS];
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(256) void t5_attn_bwd_mfma(AttnMP p) {
           const int key = t * 16 + g * 4 + r;
           float dsv = 0.f;
           if (key < Lk && q < Lq && !(p.causal && key > q)) {
-            const float x = st[r] + bcur[u][r];
+            const float x = st[r] * sscale + bcur[u][r];
             const float pr = __expf(x - lq);
             dsv = pr * (dpt[r] * drop_mult32(dc, (uint32_t)q * (uint32_t)Lk + key) - dq_);
             if (dbrow) atomicAdd(dbrow + key, dsv);
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(256) void t5_attn_bwd_mfma(AttnMP p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int q = (2 * sidx + u) * 16 + g * 4 + r;
-          bb[u][r] = p.bias ? p.bias[((long)h * Lq + (q < Lq ? q : Lq - 1)) * Lk + (key < Lk ? key : Lk - 1)] : 0.f;
+          bb[u][r] = biasp ? biasp[((long)h * Lq + (q < Lq ? q : Lq - 1)) * Lk + (key < Lk ? key : Lk - 1)] : 0.f;
         }
     };
     f32x4 bcur[2], bnxt[2];
@@ -414,7 +418,7 @@ __global__ __launch_bounds__(256) void t5_attn_bwd_mfma(AttnMP p) {
           const int q = qt * 16 + g * 4 + r;
           float pdv = 0.f, dsv = 0.f;
           if (key < Lk && q < Lq && !(p.causal && key > q)) {
-            const float x = st[r] + bcur[u][r];
+            const float x = st[r] * sscale + bcur[u][r];
             const float pr = __expf(x - lses[q]);
             const float mlt = drop_mult32(dc, (uint32_t)q * (uint32_t)Lk + key);
             pdv = pr * mlt;
@@ -510,6 +514,7 @@ static AttnMP to_mp(const klab_attn_args* a) {
   p.dctx = (const bf16_t*)a->dctx; p.lddo = a->lddo; p.dq = (bf16_t*)a->dq; p.lddq = a->lddq; p.dkk = (bf16_t*)a->dk_out; p.lddk = a->lddk;
   p.dv = (bf16_t*)a->dv; p.lddv = a->lddv; p.dbias = a->dbias; p.ds_ws = (bf16_t*)a->ds_ws;
   p.defer_reduce = a->ds_defer;
+  p.score_scale = a->score_scale; p.bias_mod = a->bias_mod;
   return p;
 }
 

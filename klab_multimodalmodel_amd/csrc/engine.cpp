@@ -122,6 +122,7 @@ struct klab_engine {
   float *sw_fmean = nullptr, *sw_frstd = nullptr;
   // swin backward scratch
   float *sdh_a = nullptr, *sdh_b = nullptr, *sdm = nullptr; void *sdy = nullptr, *sdctx = nullptr, *sdqkv = nullptr, *sda = nullptr;
+  void* sattn_ws = nullptr; size_t sattn_ws_bytes = 0;
   float *sdbias = nullptr, *sdtable = nullptr;
   // side stream: independent chains run beside the main one (frozen language encoder || Swin; weight gradients ||
   // the activation-gradient chain); joined back with events before anything the caller can observe
@@ -492,6 +493,18 @@ size_t plan_workspace(klab_engine* e, void* base, int B, int Ls, int Lt) {
     }
     e->sdbias = (float*)b.take((size_t)maxH * maxn * maxn * 4);
     e->sdtable = (float*)b.take((size_t)(4 * maxn) * maxH * 4 + (size_t)(4 * maxn) * 512 * 4);
+    e->sattn_ws = nullptr; e->sattn_ws_bytes = 0;
+    const char* ev = getenv("KLAB_SWIN_BWD_MFMA");  // "0": keep the vector-ALU window-attention backward (A/B switch)
+    if (!(ev && ev[0] == '0')) {
+      size_t need = 0;
+      for (int st = 0; st < s.n_stages; ++st) {
+        const int R = R0 >> st; const int w = R < s.window ? R : s.window;
+        const size_t x = klab_swin_attn_bwd_ws_bytes(c.dtype, B, R, w, s.heads[st], s.embed_dim << st);
+        if (x == 0) { need = 0; break; }
+        if (x > need) need = x;
+      }
+      if (need) { e->sattn_ws = b.take(need); e->sattn_ws_bytes = need; }
+    }
   }
   return (b.off + 255) & ~(size_t)255;
 }
@@ -1421,6 +1434,7 @@ int swin_backward(const Ctx& c, const float* dh0, float p_in) {
       a.dtype = c.dt; a.qkv = q.qkv; a.ctx = q.ctx; a.bias = q.bias; a.logit_scale = W[ix.ls]; a.lse = q.lse;
       a.B = B; a.R = q.R; a.w = q.w; a.shift = q.shift; a.H = q.H; a.C = C;
       a.dctx = e->sdctx; a.dqkv = e->sdqkv; a.dbias = e->sdbias; a.dlogit_scale = G(ix.ls);
+      a.bwd_ws = e->sattn_ws; a.bwd_ws_bytes = e->sattn_ws_bytes;
       RC(klab_swin_attn_bwd(&a, c.ws()));
       RC(klab_swin_cpb_bias_bwd(e->sdbias, q.bias, e->swin_index[st], e->swin_coords[st], q.hidden, W[ix.c0w], W[ix.c2w], e->sdtable, G(ix.c0w),
                                 G(ix.c0b), G(ix.c2w), e->swin_ntab[st], n, q.H, 512, c.ws()));

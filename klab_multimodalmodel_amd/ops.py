@@ -151,10 +151,16 @@ def swin_attn_fwd(qkv, ctx, bias, logit_scale, lse=None, *, B, R, w, shift, H, C
     L.check(lib.klab_swin_attn_fwd(C_byref(a), L.stream_ptr()), "klab_swin_attn_fwd")
 
 
-def swin_attn_bwd(qkv, ctx, bias, logit_scale, lse, dctx, dqkv, dbias=None, dlogit_scale=None, *, B, R, w, shift, H, C):
+def swin_attn_bwd(qkv, ctx, bias, logit_scale, lse, dctx, dqkv, dbias=None, dlogit_scale=None, *, B, R, w, shift, H, C, mfma=True):
+    """mfma=True hands the kernel its scratch (when the shape is inside the matrix-core envelope); False forces the VALU form."""
+    import torch
     lib = L.load()
     a = _swin_args(qkv, ctx, bias, logit_scale, lse, B, R, w, shift, H, C)
     a.dctx, a.dqkv, a.dbias, a.dlogit_scale = dctx.data_ptr(), dqkv.data_ptr(), L.ptr(dbias), L.ptr(dlogit_scale)
+    nbytes = lib.klab_swin_attn_bwd_ws_bytes(a.dtype, B, R, w, H, C) if mfma else 0
+    if nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=qkv.device)
+        a.bwd_ws, a.bwd_ws_bytes = ws.data_ptr(), nbytes
     L.check(lib.klab_swin_attn_bwd(C_byref(a), L.stream_ptr()), "klab_swin_attn_bwd")
 
 

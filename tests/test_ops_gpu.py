@@ -321,7 +321,7 @@ def _swin_attn_ref(qkv, bias, logit_scale, B, R, w, shift, H, C):
 
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("B,R,w,shift,H,C", [(2, 8, 4, 0, 2, 32), (2, 8, 4, 2, 2, 32), (1, 14, 7, 3, 2, 64), (2, 2, 2, 0, 8, 128),
-                                             (2, 14, 7, 0, 1, 32)])
+                                             (2, 14, 7, 0, 1, 32), (2, 28, 7, 3, 3, 96), (3, 8, 4, 2, 2, 64), (2, 7, 7, 0, 4, 128)])
 def test_swin_window_attention_fwd_bwd(ops, dt, B, R, w, shift, H, C):
     n = w * w
     qkv = rnd(B * R * R, 3 * C, seed=1).to(dt)
@@ -347,6 +347,14 @@ def test_swin_window_attention_fwd_bwd(ops, dt, B, R, w, shift, H, C):
     assert rel_l2(dbias.cpu(), br.grad) < t
     assert rel_l2(dls.cpu(), lr.grad) < t * 10  # scalar aggregated over all windows with fast-exp probabilities
     assert float(dls[0]) == 0.0
+    if dt == torch.bfloat16 and C == H * 32:  # the matrix-core backward ran above: the vector-ALU form must agree with it
+        dq2 = torch.empty_like(dqkv)
+        db2, dl2 = torch.zeros_like(dbias), torch.zeros_like(dls)
+        ops.swin_attn_bwd(dev(qkv), ctx, dev(bias), dev(ls), lse, dev(dctx), dq2, db2, dl2, mfma=False, **kw)
+        assert rel_l2(dqkv.float().cpu(), dq2.float().cpu()) < t
+        assert rel_l2(dbias.cpu(), db2.cpu()) < t
+        assert rel_l2(dls.cpu(), dl2.cpu()) < t * 10
+        assert rel_l2(dq2.float().cpu(), qr.grad) < t
 
 
 @pytest.mark.parametrize("w,H", [(4, 2), (7, 4), (2, 8)])
