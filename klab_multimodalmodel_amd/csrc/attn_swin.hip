@@ -695,21 +695,41 @@ __global__ void cpb_dtable_kernel(const float* __restrict__ dbias, const float* 
 __global__ __launch_bounds__(256) void cpb_mlp_bwd_kernel(const float* __restrict__ dtable, const float* __restrict__ coords,
                                                           const float* __restrict__ hidden, const float* __restrict__ w2, float* __restrict__ dw0,
                                                           float* __restrict__ db0, float* __restrict__ dw2, int ntab, int H, int nh) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;  // hidden unit
-  if (j >= nh) return;
+  // 16 hidden units per block x 16 slices of the table rows; fixed-order LDS reduction over the slices (bit-reproducible)
+  __shared__ float red[3][16][17];
+  const int tj = threadIdx.x & 15, tt = threadIdx.x >> 4;
+  const int j = blockIdx.x * 16 + tj;
+  const bool ok = j < nh;
   for (int h = 0; h < H; ++h) {
     float s = 0.f;
-    for (int t = 0; t < ntab; ++t) s += dtable[t * H + h] * hidden[(long)t * nh + j];
-    dw2[h * nh + j] += s;
+    if (ok)
+      for (int t = tt; t < ntab; t += 16) s += dtable[t * H + h] * hidden[(long)t * nh + j];
+    red[0][tt][tj] = s;
+    __syncthreads();
+    if (tt == 0 && ok) {
+      float a = 0.f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) a += red[0][u][tj];
+      dw2[h * nh + j] += a;
+    }
+    __syncthreads();
   }
   float a0 = 0.f, a1 = 0.f, ab = 0.f;
-  for (int t = 0; t < ntab; ++t) {
-    if (hidden[(long)t * nh + j] <= 0.f) continue;  // ReLU
-    float g = 0.f;
-    for (int h = 0; h < H; ++h) g += dtable[t * H + h] * w2[h * nh + j];
-    a0 += g * coords[t * 2]; a1 += g * coords[t * 2 + 1]; ab += g;
+  if (ok)
+    for (int t = tt; t < ntab; t += 16) {
+      if (hidden[(long)t * nh + j] <= 0.f) continue;  // ReLU
+      float g = 0.f;
+      for (int h = 0; h < H; ++h) g += dtable[t * H + h] * w2[h * nh + j];
+      a0 += g * coords[t * 2]; a1 += g * coords[t * 2 + 1]; ab += g;
+    }
+  red[0][tt][tj] = a0; red[1][tt][tj] = a1; red[2][tt][tj] = ab;
+  __syncthreads();
+  if (tt == 0 && ok) {
+    float x0 = 0.f, x1 = 0.f, xb = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { x0 += red[0][u][tj]; x1 += red[1][u][tj]; xb += red[2][u][tj]; }
+    dw0[j * 2] += x0; dw0[j * 2 + 1] += x1; db0[j] += xb;
   }
-  dw0[j * 2] += a0; dw0[j * 2 + 1] += a1; db0[j] += ab;
 }
 
 // ---- matrix-core backward (bf16, head dim 32, windows of <= 64 tokens) -------------------------------------------------------
@@ -987,7 +1007,7 @@ extern "C" int klab_swin_cpb_bias_bwd(const float* dbias, const float* bias, con
   const long tot = (long)heads * n * n;
   hipLaunchKernelGGL(cpb_dtable_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, dbias, bias, index, dtable, heads, n * n);
   KLAB_LAUNCH_CHECK();
-  hipLaunchKernelGGL(cpb_mlp_bwd_kernel, dim3((nhidden + 255) / 256), dim3(256), 0, s, dtable, coords, hidden, w2, dw0, db0, dw2, ntab, heads, nhidden);
+  hipLaunchKernelGGL(cpb_mlp_bwd_kernel, dim3((nhidden + 15) / 16), dim3(256), 0, s, dtable, coords, hidden, w2, dw0, db0, dw2, ntab, heads, nhidden);
   KLAB_LAUNCH_CHECK();
   return KLAB_OK;
 }

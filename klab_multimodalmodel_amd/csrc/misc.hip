@@ -363,6 +363,29 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, l
   if (rl == 0 && col < N) atomicAdd(out + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// bf16, 16-byte aligned rows: 8 columns per lane (one 16-byte load), 32 row-lanes per block
+__global__ __launch_bounds__(256) void colsum8_kernel(const bf16_t* __restrict__ dy, long ld, int M, int N, float* __restrict__ out) {
+  __shared__ float red[32][65];
+  const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int col = blockIdx.x * 64 + cl * 8;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (col < N)
+    for (long m = (long)blockIdx.y * 32 + rl; m < M; m += (long)gridDim.y * 32) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(dy + m * ld + col);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += (float)v[u];
+    }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) red[rl][cl * 8 + u] = a[u];
+  __syncthreads();
+  if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) t += red[r][threadIdx.x];
+    atomicAdd(out + blockIdx.x * 64 + threadIdx.x, t);
+  }
+}
+
 // ---- f32 -> T convert (optionally scaled) and f32 axpy ---------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void convert_kernel(const float* __restrict__ x, T* __restrict__ y, long n4, float scale) {
@@ -536,6 +559,14 @@ extern "C" int klab_colsum(const void* dy, long ld, int dtype, int M, int N, flo
   gy = gy < 1 ? 1 : (gy > 256 ? 256 : gy);
   dim3 grid((N + 63) / 64, gy);
   hipStream_t s = (hipStream_t)stream;
+  if (dtype == KLAB_BF16 && (N & 7) == 0 && (ld & 7) == 0 && ((uintptr_t)dy & 15) == 0) {
+    int g8 = (M + 127) / 128;  // >= 4 rows per lane
+    const int want = 2048 / (int)grid.x;  // ~8 blocks per CU over all column tiles
+    g8 = g8 < 1 ? 1 : (g8 > want ? (want < 1 ? 1 : want) : g8);
+    hipLaunchKernelGGL(colsum8_kernel, dim3(grid.x, g8), dim3(256), 0, s, (const bf16_t*)dy, ld, M, N, out);
+    KLAB_LAUNCH_CHECK();
+    return KLAB_OK;
+  }
   if (dtype == KLAB_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, ld, M, N, out);
   else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, ld, M, N, out);
   KLAB_LAUNCH_CHECK();

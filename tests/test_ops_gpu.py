@@ -468,6 +468,11 @@ def test_colsum_and_convert(ops, dt):
     out = torch.zeros(N, device="cuda")
     ops.colsum(dev(dy), out)
     assert rel_l2(out.cpu(), dy.float().sum(0)) < 1e-5
+    big = dev(rnd(5003, 288, seed=3).to(dt))  # column slices of a wider matrix (the v-bias gradient reads dqkv[:, 2C:])
+    for c0, nc in ((0, 96), (192, 96), (8, 200)):
+        o2 = torch.zeros(nc, device="cuda")
+        ops.colsum(big[:, c0:c0 + nc], o2)
+        assert rel_l2(o2.cpu(), big[:, c0:c0 + nc].float().sum(0).cpu()) < 1e-5
     x = rnd(64, 16, seed=2)
     y = torch.empty(64, 16, device="cuda", dtype=dt)
     ops.convert(dev(x), y, 0.5)
