@@ -695,39 +695,56 @@ __global__ void cpb_dtable_kernel(const float* __restrict__ dbias, const float* 
 __global__ __launch_bounds__(256) void cpb_mlp_bwd_kernel(const float* __restrict__ dtable, const float* __restrict__ coords,
                                                           const float* __restrict__ hidden, const float* __restrict__ w2, float* __restrict__ dw0,
                                                           float* __restrict__ db0, float* __restrict__ dw2, int ntab, int H, int nh) {
-  // 16 hidden units per block x 16 slices of the table rows; fixed-order LDS reduction over the slices (bit-reproducible)
-  __shared__ float red[3][16][17];
+  // 16 hidden units per block x 16 slices of the table rows (<= 12 rows per lane, kept in registers); dtable sits in LDS;
+  // one pass over the heads feeds both products, partial sums meet in LDS and are added in a fixed order (bit-reproducible)
+  constexpr int TI = 12;  // ntab <= 192 (windows up to 7x7 -> 169 entries)
+  extern __shared__ float cpb_lds[];
+  float* dt = cpb_lds;                  // [ntab, H]
+  float* red = cpb_lds + ntab * H;      // [max(H,3), 16, 17]
   const int tj = threadIdx.x & 15, tt = threadIdx.x >> 4;
   const int j = blockIdx.x * 16 + tj;
   const bool ok = j < nh;
-  for (int h = 0; h < H; ++h) {
-    float s = 0.f;
-    if (ok)
-      for (int t = tt; t < ntab; t += 16) s += dtable[t * H + h] * hidden[(long)t * nh + j];
-    red[0][tt][tj] = s;
-    __syncthreads();
-    if (tt == 0 && ok) {
-      float a = 0.f;
+  for (int i = threadIdx.x; i < ntab * H; i += 256) dt[i] = dtable[i];
+  float hv[TI], g[TI];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) a += red[0][u][tj];
-      dw2[h * nh + j] += a;
-    }
-    __syncthreads();
+  for (int i = 0; i < TI; ++i) {
+    const int t = tt + i * 16;
+    hv[i] = (ok && t < ntab) ? hidden[(long)t * nh + j] : 0.f;
+    g[i] = 0.f;
   }
-  float a0 = 0.f, a1 = 0.f, ab = 0.f;
-  if (ok)
-    for (int t = tt; t < ntab; t += 16) {
-      if (hidden[(long)t * nh + j] <= 0.f) continue;  // ReLU
-      float g = 0.f;
-      for (int h = 0; h < H; ++h) g += dtable[t * H + h] * w2[h * nh + j];
-      a0 += g * coords[t * 2]; a1 += g * coords[t * 2 + 1]; ab += g;
+  __syncthreads();
+  for (int h = 0; h < H; ++h) {
+    const float wv = ok ? w2[h * nh + j] : 0.f;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      const int t = tt + i * 16;
+      const float d = t < ntab ? dt[t * H + h] : 0.f;
+      s += d * hv[i];
+      g[i] += d * wv;
     }
-  red[0][tt][tj] = a0; red[1][tt][tj] = a1; red[2][tt][tj] = ab;
+    red[(h * 16 + tt) * 17 + tj] = s;
+  }
+  __syncthreads();
+  for (int h = tt; h < H; h += 16) {
+    float a = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) a += red[(h * 16 + u) * 17 + tj];
+    if (ok) dw2[h * nh + j] += a;
+  }
+  __syncthreads();
+  float a0 = 0.f, a1 = 0.f, ab = 0.f;
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+    const int t = tt + i * 16;
+    if (t < ntab && hv[i] > 0.f) { a0 += g[i] * coords[t * 2]; a1 += g[i] * coords[t * 2 + 1]; ab += g[i]; }  // ReLU gate
+  }
+  red[(0 * 16 + tt) * 17 + tj] = a0; red[(1 * 16 + tt) * 17 + tj] = a1; red[(2 * 16 + tt) * 17 + tj] = ab;
   __syncthreads();
   if (tt == 0 && ok) {
     float x0 = 0.f, x1 = 0.f, xb = 0.f;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) { x0 += red[0][u][tj]; x1 += red[1][u][tj]; xb += red[2][u][tj]; }
+    for (int u = 0; u < 16; ++u) { x0 += red[(0 * 16 + u) * 17 + tj]; x1 += red[(1 * 16 + u) * 17 + tj]; xb += red[(2 * 16 + u) * 17 + tj]; }
     dw0[j * 2] += x0; dw0[j * 2 + 1] += x1; db0[j] += xb;
   }
 }
@@ -1007,7 +1024,10 @@ extern "C" int klab_swin_cpb_bias_bwd(const float* dbias, const float* bias, con
   const long tot = (long)heads * n * n;
   hipLaunchKernelGGL(cpb_dtable_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, dbias, bias, index, dtable, heads, n * n);
   KLAB_LAUNCH_CHECK();
-  hipLaunchKernelGGL(cpb_mlp_bwd_kernel, dim3((nhidden + 15) / 16), dim3(256), 0, s, dtable, coords, hidden, w2, dw0, db0, dw2, ntab, heads, nhidden);
+  if (ntab > 192) return KLAB_ERR_UNSUPPORTED;  // windows above 7x7 are out of scope
+  const size_t cpb_lds = ((size_t)ntab * heads + (size_t)(heads > 3 ? heads : 3) * 16 * 17) * 4;
+  if (cpb_lds > 64 * 1024) return KLAB_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(cpb_mlp_bwd_kernel, dim3((nhidden + 15) / 16), dim3(256), cpb_lds, s, dtable, coords, hidden, w2, dw0, db0, dw2, ntab, heads, nhidden);
   KLAB_LAUNCH_CHECK();
   return KLAB_OK;
 }
