@@ -166,6 +166,23 @@ int klab_swin_attn_bwd(const klab_swin_attn_args* a, void* stream);
 int klab_swin_cpb_bias(const float* coords, const int* index, const float* w0, const float* b0, const float* w2,
                        float* table, float* hidden, float* bias, int ntab, int n, int heads, int nhidden, void* stream);
 
+/* ---- input pipeline ---------------------------------------------------------
+ * Replaces, for a batch of decoded RGB images, `Image.resize((256,256))` + `ToTensor()` (ref/modules/loader.py:15-16; Pillow
+ * ImagingResample, default BICUBIC) and `image_processor(images, return_tensors="pt")` (ref/train.py:55; ViTImageProcessor,
+ * HF/vitproc:20-27: Pillow BILINEAR to 224x224, rescale, normalise).  Every intermediate uint8 image is bit-identical to
+ * Pillow's (22-bit fixed-point weights from the same double-precision evaluation).
+ *   src: device bytes holding the images as HWC uint8 RGB; desc_dev[i] = {byte offset into src, height, width} (device).
+ *   filter_a / filter_b: PIL resampling ids of the two resizes (2 = BILINEAR, 3 = BICUBIC); filter_a = 0: src already is
+ *   the loader's [n, mid, mid, 3] uint8 batch (desc_dev / ws unused) and only the processor's part runs.
+ *   pixel_values [n, 3, out, out] f32 = (u8 * rescale - mean[c]) / std[c]; the reference's effective rescale is 1/255/255
+ *   (its processor divides the ToTensor output by 255 a second time).  mean3 / std3 are host pointers to 3 floats.
+ *   KLAB_ERR_UNSUPPORTED: other filters, or a size ratio whose weight table exceeds the LDS budget.                        */
+typedef struct klab_image_desc { long long offset; int height, width; } klab_image_desc;
+size_t klab_image_preprocess_ws_bytes(int n_images, int max_h, int mid);
+int klab_image_preprocess(const unsigned char* src, const klab_image_desc* desc_dev, int n_images, int max_h, int max_w, int mid,
+                          int out_size, int filter_a, int filter_b, double rescale, const float* mean3, const float* std3,
+                          float* pixel_values, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- glue --------------------------------------------------------------------------------- */
 /* multi-tensor f32 -> dtype cast into one arena; desc_dev: device array of
  * {const float* src; long dst_off; long n4_prefix} (prefix sums of element counts / 4)           */

@@ -80,6 +80,8 @@ SIGNATURES = {
     "klab_colsum": [vp, i64, i32, i32, i32, vp, vp],
     "klab_convert": [vp, vp, i32, i64, f32, vp],
     "klab_add_f32": [vp, vp, i64, vp],
+    "klab_image_preprocess_ws_bytes": [i32, i32, i32],
+    "klab_image_preprocess": [vp, vp, i32, i32, i32, i32, i32, i32, i32, C.c_double, vp, vp, vp, vp, C.c_size_t, vp],
 }
 
 _lib = None

@@ -1,0 +1,110 @@
+"""GPU input pipeline: the reference's per-image host work as three HIP kernels.
+
+Reference (main process, one image at a time):
+    ref/modules/loader.py:15-16   Image.open(path).convert('RGB').resize((256, 256)) ; ToTensor()
+    ref/train.py:55               images = image_processor(images, return_tensors="pt").to(device_id)
+Here JPEG decoding stays with PIL (no decoder on the device); everything after it -- both Pillow resizes, the float
+conversion, the processor's rescale (twice, as the reference effectively does) and normalisation -- runs on the GPU and is
+bit-identical to Pillow at every uint8 stage (`csrc/image_pre.hip`).  Two entry points:
+
+    GpuImageProcessor()(images)                 drop-in for `image_processor(images, return_tensors="pt")`: `images` is the
+                                                DataLoader's [B, 3, 256, 256] float batch in [0, 1] (or a list of such CHW tensors)
+    GpuImageProcessor().from_decoded(arrays)    list of decoded HWC uint8 RGB images of ANY size (numpy / PIL.Image / tensor):
+                                                replaces loader.py:15-16 as well (use `DatasetLoader(decode_only=True)`)
+
+Both return {"pixel_values": cuda float32 [B, 3, 224, 224]} -- what `MyModel.forward` takes.  No CPU fallback: without the HIP
+library the call raises.
+"""
+import numpy as np
+import torch
+
+from .. import ops
+
+BILINEAR, BICUBIC = 2, 3
+
+
+class BatchFeature(dict):
+    """the `.to(device)`-able mapping `image_processor(...)` returns (ref/train.py:55 calls `.to(device_id)` on it)"""
+
+    def to(self, device):
+        return BatchFeature({k: v.to(device) for k, v in self.items()})
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+class GpuImageProcessor:
+    def __init__(self, size=224, resample=BILINEAR, rescale_factor=1 / 255, image_mean=(0.5, 0.5, 0.5), image_std=(0.5, 0.5, 0.5),
+                 loader_size=256, loader_resample=BICUBIC, device="cuda"):
+        """defaults = `ViTImageProcessor()` (HF/vitproc:20-27) behind the reference loader's 256x256 BICUBIC resize"""
+        if isinstance(size, dict):
+            if size["height"] != size["width"]:
+                raise NotImplementedError("square outputs only")
+            size = size["height"]
+        self.size, self.resample = int(size), int(resample)
+        self.mean, self.std = tuple(float(m) for m in image_mean), tuple(float(s) for s in image_std)
+        self.loader_size, self.loader_resample = int(loader_size), int(loader_resample)
+        # the processor turns [0,1] floats back into uint8 for Pillow, scales the result by 1/255 and THEN applies do_rescale
+        self.rescale = (1.0 / 255.0) * float(rescale_factor)
+        self.device = torch.device(device)
+
+    @classmethod
+    def from_pretrained(cls, path=None, **kw):
+        """reads `preprocessor_config.json` from a local directory when given one (no hub access here)"""
+        import json
+        import os
+        cfg = {}
+        if path and os.path.isdir(path) and os.path.exists(os.path.join(path, "preprocessor_config.json")):
+            with open(os.path.join(path, "preprocessor_config.json")) as f:
+                cfg = json.load(f)
+        keys = ("size", "resample", "rescale_factor", "image_mean", "image_std")
+        return cls(**{**{k: cfg[k] for k in keys if k in cfg}, **kw})
+
+    def _out(self, n):
+        return torch.empty(n, 3, self.size, self.size, dtype=torch.float32, device=self.device)
+
+    def __call__(self, images, return_tensors="pt"):
+        if return_tensors != "pt":
+            raise ValueError("return_tensors must be 'pt'")
+        if isinstance(images, (list, tuple)):
+            images = torch.stack([torch.as_tensor(i) for i in images])
+        if images.dim() == 3:
+            images = images.unsqueeze(0)
+        if images.dtype == torch.uint8:
+            raise TypeError("uint8 images: use from_decoded() (HWC, any size)")
+        B, C, H, W = images.shape
+        if C != 3 or H != W:
+            raise ValueError("expected [B, 3, S, S] float images in [0, 1] (the reference DataLoader's batches)")
+        # [0,1] floats -> the uint8 image Pillow sees (HF to_pil_image: x * 255 -> uint8, truncating; exact for k / 255)
+        u8 = (images.to(self.device, non_blocking=True) * 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+        pv = self._out(B)
+        ops.image_preprocess(u8, None, B, H, W, pv, mid=H, out=self.size, filter_a=0, filter_b=self.resample, rescale=self.rescale,
+                             mean=self.mean, std=self.std)
+        return BatchFeature(pixel_values=pv)
+
+    def from_decoded(self, images):
+        """list of decoded RGB images (HWC uint8 numpy arrays, PIL images or tensors) of any size"""
+        arrs = [np.asarray(im.convert("RGB") if hasattr(im, "convert") else im, dtype=np.uint8) for im in images]
+        for a in arrs:
+            if a.ndim != 3 or a.shape[2] != 3:
+                raise ValueError("expected HWC RGB uint8 images")
+        n = len(arrs)
+        sizes = [a.shape[0] * a.shape[1] * 3 for a in arrs]
+        offs = np.concatenate([[0], np.cumsum([(s + 15) // 16 * 16 for s in sizes])]).astype(np.int64)
+        host = torch.empty(int(offs[-1]), dtype=torch.uint8).pin_memory() if self.device.type == "cuda" else torch.empty(int(offs[-1]), dtype=torch.uint8)
+        hb = host.numpy()
+        desc = np.zeros((n, 2), np.int64)
+        for i, a in enumerate(arrs):
+            hb[offs[i]:offs[i] + sizes[i]] = a.reshape(-1)
+            desc[i, 0] = offs[i]
+            desc[i, 1] = a.shape[0] | (a.shape[1] << 32)  # {int height, width} little-endian
+        src = host.to(self.device, non_blocking=True)
+        dd = torch.from_numpy(desc).to(self.device, non_blocking=True)
+        pv = self._out(n)
+        ops.image_preprocess(src, dd, n, max(a.shape[0] for a in arrs), max(a.shape[1] for a in arrs), pv, mid=self.loader_size,
+                             out=self.size, filter_a=self.loader_resample, filter_b=self.resample, rescale=self.rescale, mean=self.mean,
+                             std=self.std)
+        return BatchFeature(pixel_values=pv)

@@ -239,3 +239,20 @@ def colsum(dy, out):
 def convert(x, y, scale=1.0):
     lib = L.load()
     L.check(lib.klab_convert(x.data_ptr(), y.data_ptr(), L.dtype_code(y.dtype), x.numel(), scale, L.stream_ptr()), "klab_convert")
+
+
+def image_preprocess(src_u8, desc, n, max_h, max_w, pixel_values, *, mid=256, out=224, filter_a=3, filter_b=2,
+                     rescale=1.0 / 255 / 255, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5)):
+    """klab_image_preprocess: src_u8 device uint8 bytes, desc device int64 [n, 2] rows of {offset, height | width << 32}
+    (the klab_image_desc layout), or filter_a=0 with src_u8 = [n, mid, mid, 3]."""
+    import torch
+    lib = L.load()
+    m3 = (C.c_float * 3)(*mean)
+    s3 = (C.c_float * 3)(*std)
+    ws, nbytes = None, 0
+    if filter_a:
+        nbytes = lib.klab_image_preprocess_ws_bytes(n, max_h, mid)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=src_u8.device)
+    L.check(lib.klab_image_preprocess(src_u8.data_ptr(), L.ptr(desc), n, max_h, max_w, mid, out, filter_a, filter_b, rescale,
+                                      C.cast(m3, C.c_void_p), C.cast(s3, C.c_void_p), pixel_values.data_ptr(), L.ptr(ws), nbytes,
+                                      L.stream_ptr()), "klab_image_preprocess")
