@@ -94,7 +94,18 @@ class GpuImageProcessor:
         n = len(arrs)
         sizes = [a.shape[0] * a.shape[1] * 3 for a in arrs]
         offs = np.concatenate([[0], np.cumsum([(s + 15) // 16 * 16 for s in sizes])]).astype(np.int64)
-        host = torch.empty(int(offs[-1]), dtype=torch.uint8).pin_memory() if self.device.type == "cuda" else torch.empty(int(offs[-1]), dtype=torch.uint8)
+        total = int(offs[-1])
+        # two pinned staging buffers, grown on demand and alternated: the async H2D copy of batch i may still be reading one
+        # while batch i+1 is packed into the other (pinning per call costs more than the whole pipeline)
+        self._flip = 1 - getattr(self, "_flip", 0)
+        stage = getattr(self, "_stage", None) or [None, None]
+        if stage[self._flip] is None or stage[self._flip].numel() < total:
+            stage[self._flip] = torch.empty(max(total, 1), dtype=torch.uint8).pin_memory()
+        self._stage = stage
+        ev = getattr(self, "_stage_ev", None) or [None, None]
+        if ev[self._flip] is not None:
+            ev[self._flip].synchronize()  # the copy that last used this buffer has finished
+        host = stage[self._flip][:total]
         hb = host.numpy()
         desc = np.zeros((n, 2), np.int64)
         for i, a in enumerate(arrs):
@@ -102,7 +113,10 @@ class GpuImageProcessor:
             desc[i, 0] = offs[i]
             desc[i, 1] = a.shape[0] | (a.shape[1] << 32)  # {int height, width} little-endian
         src = host.to(self.device, non_blocking=True)
-        dd = torch.from_numpy(desc).to(self.device, non_blocking=True)
+        ev[self._flip] = torch.cuda.Event()
+        ev[self._flip].record()
+        self._stage_ev = ev
+        dd = torch.from_numpy(desc).to(self.device)
         pv = self._out(n)
         ops.image_preprocess(src, dd, n, max(a.shape[0] for a in arrs), max(a.shape[1] for a in arrs), pv, mid=self.loader_size,
                              out=self.size, filter_a=self.loader_resample, filter_b=self.resample, rescale=self.rescale, mean=self.mean,

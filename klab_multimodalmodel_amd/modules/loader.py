@@ -44,11 +44,18 @@ def span_mask(caption: str):
 
 
 class DatasetLoader(torch.utils.data.Dataset):
+    # decode_only (klab extension): __getitem__ returns the decoded HWC uint8 RGB image at its own size; the
+    # 256x256 resize, ToTensor and the image processor then run on the GPU (`modules.image_pipeline.GpuImageProcessor
+    # .from_decoded`, bit-identical to Pillow).  Batches of such items need `collate_decoded` (images stay a list).
+    decode_only = False
+
     def __init__(self):
         self.images, self.tgt_texts, self.src_texts = [], [], []
         self.transform = pil_to_tensor01
 
     def _load_image(self, path):
+        if self.decode_only:
+            return torch.from_numpy(np.asarray(Image.open(path).convert('RGB'), dtype=np.uint8).copy())
         return self.transform(Image.open(path).convert('RGB').resize((256, 256)))
 
     def __getitem__(self, idx):
@@ -89,6 +96,12 @@ class RedCapsDatasetLoader(DatasetLoader):
         return self._load_image(self.images[idx]), src, tgt
 
 
+def collate_decoded(batch):
+    """collate_fn for `decode_only` datasets: (list of HWC uint8 tensors, list of src texts, list of tgt texts)"""
+    images, src, tgt = zip(*batch)
+    return list(images), list(src), list(tgt)
+
+
 def get_dataloader(args, phase, rank):
     name = args.data_dir.lower()
     if 'mscoco' in name:
@@ -100,5 +113,7 @@ def get_dataloader(args, phase, rank):
     # the reference sizes the sampler by the LOCAL device count and never calls set_epoch: kept
     sampler = torch.utils.data.distributed.DistributedSampler(dataset, num_replicas=torch.cuda.device_count(), rank=rank,
                                                               shuffle=True, drop_last=True)
-    return torch.utils.data.DataLoader(dataset, batch_size=args.batch_size, num_workers=os.cpu_count() // 4, pin_memory=True,
-                                       sampler=sampler)
+    gpu_pre = bool(getattr(args, 'gpu_preprocess', False))  # klab extension; the reference has no such flag (default off)
+    dataset.decode_only = gpu_pre
+    return torch.utils.data.DataLoader(dataset, batch_size=args.batch_size, num_workers=os.cpu_count() // 4, pin_memory=not gpu_pre,
+                                       sampler=sampler, collate_fn=collate_decoded if gpu_pre else None)
