@@ -64,6 +64,9 @@ __device__ inline Span pil_coeffs(int in_size, int out_size, int f, int xx, int*
 
 __device__ __forceinline__ unsigned char clip8(int v) {
   v >>= PBITS;
+  // keep shift and clamp apart: fused into gfx950's v_ashr_pk_u8_i32 (when two results are packed) the low bit came out
+  // different from floor(v / 2^22) clamped -- measured as +1 errors against Pillow in the 32-bit vertical pass
+  asm volatile("" : "+v"(v));
   return (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
 }
 
@@ -105,15 +108,17 @@ __global__ __launch_bounds__(256) void resample_h_kernel(ImgP p) {
   }
 }
 
+// vertical pass: 8 output rows per block; a thread owns 4 consecutive bytes of the row (one 32-bit load per source row)
 constexpr int VROWS = 8;
 __global__ __launch_bounds__(256) void resample_v_kernel(ImgP p) {
-  extern __shared__ int lds_v[];  // k[VROWS][kmax] | lo[VROWS] | n[VROWS]
+  extern __shared__ __attribute__((aligned(16))) int lds_v[];  // k[VROWS][kmax] | lo[VROWS] | n[VROWS]
   const klab_image_desc d = p.desc[blockIdx.y];
   const int mid = p.mid, y0 = blockIdx.x * VROWS;
   int* kk = lds_v;
   int* lo = kk + VROWS * p.kmax;
   int* nn = lo + VROWS;
-  if (threadIdx.x < VROWS && y0 + (int)threadIdx.x < mid) {
+  const int nout = y0 + VROWS <= mid ? VROWS : mid - y0;
+  if ((int)threadIdx.x < nout) {
     const Span s = pil_coeffs(d.height, mid, p.filter_a, y0 + threadIdx.x, kk + threadIdx.x * p.kmax, 1);
     lo[threadIdx.x] = s.lo; nn[threadIdx.x] = s.n;
   }
@@ -121,12 +126,28 @@ __global__ __launch_bounds__(256) void resample_v_kernel(ImgP p) {
   const int rowb = mid * 3;
   const unsigned char* src = p.tmp + (size_t)blockIdx.y * p.max_h * rowb;
   unsigned char* dst = p.mid_img + (size_t)blockIdx.y * mid * rowb;
-  for (int r = 0; r < VROWS && y0 + r < mid; ++r) {
-    const int l = lo[r], n = nn[r];
+  if ((rowb & 3) == 0) {  // row pitch and all bases are 4-byte aligned (workspace regions are 256-byte aligned)
+    for (int e = threadIdx.x * 4; e < rowb; e += 1024) {
+      for (int r = 0; r < nout; ++r) {
+        const int* k = kk + r * p.kmax;
+        const int lr = lo[r], nr = nn[r];
+        int a0 = 1 << (PBITS - 1), a1 = a0, a2 = a0, a3 = a0;
+        for (int t = 0; t < nr; ++t) {
+          const unsigned int v = *reinterpret_cast<const unsigned int*>(src + (size_t)(lr + t) * rowb + e);
+          const int kt = k[t];
+          a0 += (int)(v & 255u) * kt; a1 += (int)((v >> 8) & 255u) * kt; a2 += (int)((v >> 16) & 255u) * kt; a3 += (int)(v >> 24) * kt;
+        }
+        const unsigned int o = (unsigned int)clip8(a0) | ((unsigned int)clip8(a1) << 8) | ((unsigned int)clip8(a2) << 16) | ((unsigned int)clip8(a3) << 24);
+        *reinterpret_cast<unsigned int*>(dst + (size_t)(y0 + r) * rowb + e) = o;
+      }
+    }
+    return;
+  }
+  for (int r = 0; r < nout; ++r) {
     const int* k = kk + r * p.kmax;
     for (int e = threadIdx.x; e < rowb; e += 256) {
       int s = 1 << (PBITS - 1);
-      for (int t = 0; t < n; ++t) s += src[(size_t)(l + t) * rowb + e] * k[t];
+      for (int t = 0; t < nn[r]; ++t) s += src[(size_t)(lo[r] + t) * rowb + e] * k[t];
       dst[(size_t)(y0 + r) * rowb + e] = clip8(s);
     }
   }
@@ -139,7 +160,7 @@ struct NormP {
 };
 
 __global__ __launch_bounds__(256) void resize_norm_kernel(NormP p) {
-  extern __shared__ int lds_n[];  // kx[kb][osz] | lox[osz] | nx[osz] | ky[tr][kb] | loy[tr] | ny[tr] | tile u8 [nr_max][osz*3]
+  extern __shared__ int lds_n[];  // kx[kb][osz] | lox[osz] | nx[osz] | ky[tr][kb] | loy[tr] | ny[tr] | lut f32 [3][256] | tile u8 [nr_max][osz*3]
   const int osz = p.osz, mid = p.mid, kb = p.kb, tr = p.tr;
   int* kx = lds_n;
   int* lox = kx + kb * osz;
@@ -147,7 +168,8 @@ __global__ __launch_bounds__(256) void resize_norm_kernel(NormP p) {
   int* ky = nx + osz;
   int* loy = ky + tr * kb;
   int* ny = loy + tr;
-  unsigned char* tile = reinterpret_cast<unsigned char*>(ny + tr);
+  float* lut = reinterpret_cast<float*>(ny + tr);
+  unsigned char* tile = reinterpret_cast<unsigned char*>(lut + 768);
   const int y0 = blockIdx.x * tr;
   const int rows = y0 + tr <= osz ? tr : osz - y0;
   for (int xx = threadIdx.x; xx < osz; xx += 256) {
@@ -157,6 +179,10 @@ __global__ __launch_bounds__(256) void resize_norm_kernel(NormP p) {
   if ((int)threadIdx.x < rows) {
     const Span s = pil_coeffs(mid, osz, p.filter_b, y0 + threadIdx.x, ky + threadIdx.x * kb, 1);
     loy[threadIdx.x] = s.lo; ny[threadIdx.x] = s.n;
+  }
+  for (int i = threadIdx.x; i < 768; i += 256) {  // (u8 * rescale - mean) / std evaluated once per value, in double
+    const int c = i >> 8;
+    lut[i] = (float)(((double)(i & 255) * p.rescale - p.mean[c]) / p.stdv[c]);
   }
   __syncthreads();
   const int r_lo = loy[0], r_hi = loy[rows - 1] + ny[rows - 1];  // source rows this tile needs (bounds grow with the index)
@@ -186,8 +212,7 @@ __global__ __launch_bounds__(256) void resize_norm_kernel(NormP p) {
     const int* k = ky + r * kb;
     int s = 1 << (PBITS - 1);
     for (int t = 0; t < n; ++t) s += tile[(l + t) * rowb + xx * 3 + c] * k[t];
-    const double v = ((double)clip8(s) * p.rescale - p.mean[c]) / p.stdv[c];
-    out[((size_t)c * osz + (y0 + r)) * osz + xx] = (float)v;
+    out[((size_t)c * osz + (y0 + r)) * osz + xx] = lut[c * 256 + clip8(s)];
   }
 }
 
@@ -239,7 +264,7 @@ extern "C" int klab_image_preprocess(const unsigned char* src, const klab_image_
   if (q.nr_max > mid) q.nr_max = mid;
   q.rescale = rescale;
   for (int c = 0; c < 3; ++c) { q.mean[c] = mean3[c]; q.stdv[c] = std3[c]; }
-  const size_t lds_n = ((size_t)q.kb * out_size + 2 * (size_t)out_size + (size_t)q.tr * q.kb + 2 * q.tr) * 4 + (size_t)q.nr_max * out_size * 3;
+  const size_t lds_n = ((size_t)q.kb * out_size + 2 * (size_t)out_size + (size_t)q.tr * q.kb + 2 * q.tr + 768) * 4 + (size_t)q.nr_max * out_size * 3;
   if (lds_n > 64 * 1024) return KLAB_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(resize_norm_kernel, dim3((out_size + q.tr - 1) / q.tr, n_images), dim3(256), lds_n, s, q);
   KLAB_LAUNCH_CHECK();
