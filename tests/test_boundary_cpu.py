@@ -211,3 +211,38 @@ def test_fused_adam_falls_back_to_torch_adam_for_foreign_parameters():
             o.zero_grad()
     assert ob._fallback is not None
     assert torch.equal(a.detach(), b.detach())
+
+
+def test_async_checkpointer_roundtrip_and_reference_schema(built, tmp_path):
+    """AsyncCheckpointer writes the reference's {'transformer', 'image_model'} schema (loadable by MyModel.load,
+    ref/models/model.py:36-42) plus optimizer / scheduler / step; load_checkpoint restores all of it."""
+    from klab_multimodalmodel_amd.checkpoint import AsyncCheckpointer, load_checkpoint
+    from klab_multimodalmodel_amd.models.model import MyModel
+    sw, t5 = _tiny()
+    a = _args(True)
+    a.result_dir = str(tmp_path)
+    m = MyModel(a, _configs=(sw, t5, t5), _seed=1)
+    opt = torch.optim.Adam(m.transformer.parameters(), lr=1e-3)
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=1, gamma=0.5)
+    for p in m.transformer.parameters():
+        p.grad = torch.ones_like(p)
+    opt.step(); sched.step()
+    ck = AsyncCheckpointer(str(tmp_path))
+    path = ck.save(m, opt, sched, step=7, name="ck.pth")
+    ck.wait()
+    assert os.path.exists(path) and not os.path.exists(path + ".tmp")
+    raw = torch.load(path, weights_only=False)
+    assert set(raw) >= {"transformer", "image_model", "optimizer", "scheduler", "step"} and raw["step"] == 7
+    m2 = MyModel(a, _configs=(sw, t5, t5), _seed=2)
+    m2.load("ck.pth")  # the reference-schema loader reads the same file
+    for (k, x), (_, y) in zip(m.transformer.state_dict().items(), m2.transformer.state_dict().items()):
+        assert torch.equal(x, y), k
+    m3 = MyModel(a, _configs=(sw, t5, t5), _seed=3)
+    opt3 = torch.optim.Adam(m3.transformer.parameters(), lr=1e-3)
+    sched3 = torch.optim.lr_scheduler.StepLR(opt3, step_size=1, gamma=0.5)
+    assert load_checkpoint(path, m3, opt3, sched3) == 7
+    assert opt3.param_groups[0]["lr"] == opt.param_groups[0]["lr"] == 5e-4
+    s, s3 = opt.state_dict()["state"], opt3.state_dict()["state"]
+    assert s.keys() == s3.keys() and all(torch.equal(s[k]["exp_avg"], s3[k]["exp_avg"]) for k in s)
+    for (k, x), (_, y) in zip(m.image_model.state_dict().items(), m3.image_model.state_dict().items()):
+        assert torch.equal(x, y), k
