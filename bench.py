@@ -111,7 +111,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist_on = world > 1
+    dist_on = world > 1 or os.environ.get("KLAB_BENCH_FORCE_DIST") == "1"  # the latter: rehearse the N>1 code path with one rank
     if a.gpus != world and dist_on:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)

@@ -9,6 +9,7 @@ on a side HIP stream, overlapping the next segment's backward; the last reduce i
 Semantics kept from torch DDP: parameters broadcast from rank 0 at construction, gradients averaged
 over ranks, every micro-step reduces (the reference never uses no_sync).
 """
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -45,7 +46,9 @@ class SegmentReducer:
         return out
 
     def reduce_segment(self, seg: int, flats):
-        if self.world == 1:
+        # KLAB_DDP_FORCE_COLLECTIVE=1: issue the collectives even in a one-rank group (test hook: exercises the comm-stream /
+        # RCCL path on a single GPU; the mean over one rank is the identity)
+        if self.world == 1 and not (dist.is_initialized() and os.environ.get("KLAB_DDP_FORCE_COLLECTIVE") == "1"):
             return
         for model, off, n in self.buckets(seg):
             flat = flats.get(model)

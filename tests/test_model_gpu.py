@@ -221,6 +221,14 @@ def test_reference_training_loop_under_stock_ddp_and_klab_ddp():
             l1, w1, s1 = _train_steps("torch", acc)
             l2, w2, s2 = _train_steps("klab", acc)
             l3, w3, _s3 = _train_steps("klab", acc, fused_adam=True)  # klab DDP + klab FusedAdam (what bench.py runs at N > 1)
+            os.environ["KLAB_DDP_FORCE_COLLECTIVE"] = "1"  # same, with the RCCL all-reduces really issued on the comm stream
+            try:
+                l4, w4, _s4 = _train_steps("klab", acc, fused_adam=True)
+            finally:
+                del os.environ["KLAB_DDP_FORCE_COLLECTIVE"]
+            assert max(abs(x - y) for x, y in zip(l0, l4)) < 2e-4, (acc, l0, l4)
+            for k in w0:
+                assert rel_l2(w4[k].cpu(), w0[k].cpu()) < 2e-3, k
             assert max(abs(x - y) for x, y in zip(l0, l3)) < 2e-4, (acc, l0, l3)
             for k in w0:
                 assert rel_l2(w3[k].cpu(), w0[k].cpu()) < 2e-3, k
