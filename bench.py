@@ -23,6 +23,7 @@ import types
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # see klab_multimodalmodel_amd/__init__.py: streams must not share HW queues
 import torch  # noqa: E402
 
 GFLOP_PER_SAMPLE = {"cfg2": 27.26}  # fwd+bwd algorithmic work, SURVEY §8d / BASELINE.md §3
@@ -111,7 +112,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist_on = world > 1 or os.environ.get("KLAB_BENCH_FORCE_DIST") == "1"  # the latter: rehearse the N>1 code path with one rank
+    dist_on = world > 1 or os.environ.get("KLAB_BENCH_FORCE_DIST") in ("1", "2")  # the latter: rehearse the N>1 code path with one rank
     if a.gpus != world and dist_on:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
@@ -127,7 +128,7 @@ def main():
                                  image_model_train=False, transformer_model_name="t5-small")
     torch.manual_seed(0)
     model = MyModel(args, _configs=(sw, t5, t5), _seed=0, dtype="bf16").to(dev)
-    if dist_on:
+    if dist_on and os.environ.get("KLAB_BENCH_FORCE_DIST") != "2":  # "2": process group without the wrapper (diagnostic)
         from klab_multimodalmodel_amd.ddp import DistributedDataParallel as DDP
         model = DDP(model, device_ids=[local_rank])
         core = model.module
@@ -164,10 +165,14 @@ def main():
     for _ in range(a.steps):
         loss = step()
     host_ms = (time.perf_counter() - t0) / a.steps * 1e3  # host time to ENQUEUE a step (no device wait): < ms_per_step => GPU-bound
+    torch.cuda.synchronize()
+    t_sync = time.perf_counter()
     if dist_on:
         dist.barrier()
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if dist_on and rank == 0:
+        print(f"[bench] closing barrier took {(time.perf_counter() - t_sync) * 1e3:.2f} ms", file=sys.stderr, flush=True)
     if dist_on:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
