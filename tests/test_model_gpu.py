@@ -402,6 +402,45 @@ def test_checkpoint_resume_with_fused_adam(tmp_path):
 
 
 @pytest.mark.gpu
+def test_full_batch_properties_at_bench_size():
+    """BASELINE configs[1] at its full size (B=64, Ls=9, Lt=64, bf16) has no oracle run that finishes in seconds, so the hot path
+    is checked through size-independent properties: (1) the mean-token loss and the gradients of the whole batch equal the
+    average over its two halves (same token counts; eval mode, so no dropout); (2) backward is linear in d(loss);
+    (3) a repeated forward reproduces the loss bit for bit."""
+    import bench
+    from klab_multimodalmodel_amd.models.model import MyModel
+    sw, t5 = bench.cfg2_configs()
+    args = types.SimpleNamespace(result_dir="/tmp", language_model_name="-", image_model_name="-", image_model_train=False,
+                                 transformer_model_name="-")
+    m = MyModel(args, _configs=(sw, t5, t5), _seed=0, dtype="bf16").to("cuda")
+    m._direct_grads = True
+    m.transformer.eval()
+    B = 64
+    pix, src, tgt = bench.synth_batch(B, 9, 64, 224, 32128, "cuda", seed=77)
+
+    def run_part(sl, scale=1.0):
+        for p in m.transformer.parameters():
+            p.grad = None
+        loss = m({"pixel_values": pix[sl]}, {"input_ids": src[sl]}, {"input_ids": tgt[sl]})
+        (loss * scale).backward()
+        return float(loss), torch.cat([p.grad.flatten() for p in m.transformer.parameters() if p.grad is not None]).double().clone()
+
+    l_full, g_full = run_part(slice(0, B))
+    l_again, _ = run_part(slice(0, B))
+    assert l_full == l_again
+    l_a, g_a = run_part(slice(0, B // 2))
+    l_b, g_b = run_part(slice(B // 2, B))
+    assert abs(l_full - 0.5 * (l_a + l_b)) <= 1e-3 * abs(l_full), (l_full, l_a, l_b)
+    g_avg = 0.5 * (g_a + g_b)
+    cos = float(torch.dot(g_full, g_avg) / (g_full.norm() * g_avg.norm()))
+    assert cos > 0.999, cos
+    assert abs(float(g_full.norm() / g_avg.norm()) - 1.0) < 2e-2
+    _, g_2 = run_part(slice(0, B), scale=2.0)
+    cos2 = float(torch.dot(g_full, g_2) / (g_full.norm() * g_2.norm()))
+    assert cos2 > 0.9995 and abs(float(g_2.norm() / g_full.norm()) - 2.0) < 2e-2, (cos2, float(g_2.norm() / g_full.norm()))
+
+
+@pytest.mark.gpu
 def test_async_sharded_checkpoint_resume(tmp_path):
     """AsyncCheckpointer (snapshot on a side stream, background write, Adam moments sharded over 2 ranks) +
     load_checkpoint: 2 steps, save, fresh model, load, 2 more == 4 uninterrupted steps; training continues while the file is written."""
