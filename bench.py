@@ -130,7 +130,7 @@ def main():
     model = MyModel(args, _configs=(sw, t5, t5), _seed=0, dtype="bf16").to(dev)
     if dist_on and os.environ.get("KLAB_BENCH_FORCE_DIST") != "2":  # "2": process group without the wrapper (diagnostic)
         from klab_multimodalmodel_amd.ddp import DistributedDataParallel as DDP
-        model = DDP(model, device_ids=[local_rank])
+        model = DDP(model, device_ids=[local_rank], overlap_optimizer=(a.optimizer == "klab" and os.environ.get("KLAB_BENCH_OVERLAP_OPT", "1") == "1"))
         core = model.module
     else:
         core = model

@@ -287,6 +287,14 @@ int klab_engine_adam_step(klab_engine* e, float* m, float* v, float lr, float be
 /* the kernel behind it: desc = device array of {float* p; long grad_off; long arena_off (<0: none); long n4_prefix} */
 int klab_adam_step(const void* desc_dev, int ndesc, long total4, const float* grads, float* m, float* v, void* arena, int dtype, float lr,
                    float beta1, float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, void* stream);
+/* the same update restricted to the tensors of ONE backward segment (0: decoder + tied embedding, 1: encoder): under data
+ * parallelism segment 0 can be updated while segment 1's gradient all-reduce is still in flight.  Both segments = one full step. */
+int klab_engine_adam_step_segment(klab_engine* e, int segment, float* m, float* v, float lr, float beta1, float beta2, float eps,
+                                  float weight_decay, float bias_corr1, float bias_corr2, void* stream);
+/* vec4 range [begin4, end4) of the descriptor table's prefix space */
+int klab_adam_step_range(const void* desc_dev, int ndesc, long begin4, long end4, const float* grads, float* m, float* v, void* arena,
+                         int dtype, float lr, float beta1, float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,
+                         void* stream);
 /* segment 0: LM head + decoder + tied embedding; 1: encoder; 2: Swin (no-op unless train_swin).
  * dloss_dev: device scalar d(objective)/d(loss) (NULL = 1).                                       */
 int klab_engine_backward(klab_engine* e, int segment, const float* dloss_dev, void* stream);

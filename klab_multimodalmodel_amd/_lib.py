@@ -54,6 +54,7 @@ SIGNATURES = {
     "klab_rmsnorm_part_rows": [i32],
     "klab_colpart_reduce": [vp, i64, i32, i32, vp, i32, vp],
     "klab_adam_step": [vp, i32, i64, vp, vp, vp, vp, i32, f32, f32, f32, f32, f32, f32, f32, vp],
+    "klab_adam_step_range": [vp, i32, i64, i64, vp, vp, vp, vp, i32, f32, f32, f32, f32, f32, f32, f32, vp],
     "klab_layernorm_fwd": [vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, f32, i32, i32, i32, f32, vp, u32, vp],
     "klab_layernorm_bwd": [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, u32, vp],
     "klab_t5_attn_fwd": [C.POINTER(AttnArgs), vp],

@@ -98,7 +98,7 @@ struct klab_engine {
   float* G[3] = {nullptr, nullptr, nullptr};
   void* warena = nullptr; float* farena = nullptr;
   void* cast_desc = nullptr; int n_cast = 0; long cast_total4 = 0;      // trainable GEMM weights (cast every forward)
-  void* adam_desc = nullptr; int n_adam = 0; long adam_total4 = 0;        // fused optimizer step over the trainable T5 (f-2)
+  void* adam_desc = nullptr; int n_adam = 0; long adam_total4 = 0, adam_split4 = 0;        // fused optimizer step over the trainable T5 (f-2)
   // RMS-norm weight gradients of a stack: per-workgroup partials of every norm, folded by one reduction per stack
   float* rms_part = nullptr; long rms_part_stride = 0; float** rms_dst_dev[2] = {nullptr, nullptr}; int rms_ncalls[2] = {0, 0};
   void* cast_desc_frozen = nullptr; int n_cast_frozen = 0; long cast_total4_frozen = 0;  // frozen towers (cast when dirty)
@@ -1027,12 +1027,17 @@ extern "C" int klab_engine_bind(klab_engine* e, int B, int Ls, int Lt, void* wor
     std::vector<long> d;
     long pre = 0; int n = 0;
     bool ok = true;
-    for (size_t i = 0; i < e->P[2].size(); ++i) {
-      const ParamInfo& p = e->P[2][i];
-      if (p.grad_off < 0) continue;
-      if (p.numel % 4 || (p.grad_off & 3) || (p.warena_off >= 0 && (p.warena_off & 3))) { ok = false; break; }
-      d.push_back((long)e->W[2][i]); d.push_back(p.grad_off); d.push_back(p.warena_off); d.push_back(pre);
-      pre += p.numel / 4; ++n;
+    // tensors of backward segment 0 first, then segment 1: a prefix range of the table = one segment (the optimizer may
+    // update segment 0 while segment 1's gradient all-reduce is still in flight, klab_engine_adam_step_segment)
+    for (int seg = 0; seg < 2 && ok; ++seg) {
+      if (seg == 1) e->adam_split4 = pre;
+      for (size_t i = 0; i < e->P[2].size(); ++i) {
+        const ParamInfo& p = e->P[2][i];
+        if (p.grad_off < 0 || (p.grad_off >= e->seg_off[1]) != (seg == 1)) continue;
+        if (p.numel % 4 || (p.grad_off & 3) || (p.warena_off >= 0 && (p.warena_off & 3))) { ok = false; break; }
+        d.push_back((long)e->W[2][i]); d.push_back(p.grad_off); d.push_back(p.warena_off); d.push_back(pre);
+        pre += p.numel / 4; ++n;
+      }
     }
     e->n_adam = ok ? n : 0; e->adam_total4 = pre;
     if (e->n_adam) {
@@ -1182,6 +1187,15 @@ extern "C" int klab_engine_adam_step(klab_engine* e, float* m, float* v, float l
   if (!e->n_adam) return KLAB_ERR_UNSUPPORTED;
   return klab_adam_step(e->adam_desc, e->n_adam, e->adam_total4, e->G[2], m, v, e->warena, e->cfg.dtype, lr, beta1, beta2, eps, weight_decay,
                         bias_corr1, bias_corr2, stream);
+}
+
+extern "C" int klab_engine_adam_step_segment(klab_engine* e, int segment, float* m, float* v, float lr, float beta1, float beta2, float eps,
+                                             float weight_decay, float bias_corr1, float bias_corr2, void* stream) {
+  if (!e || !e->bound || !m || !v || !e->G[2] || segment < 0 || segment > 1) return KLAB_ERR_BADARG;
+  if (!e->n_adam) return KLAB_ERR_UNSUPPORTED;
+  const long b4 = segment == 0 ? 0 : e->adam_split4, e4 = segment == 0 ? e->adam_split4 : e->adam_total4;
+  return klab_adam_step_range(e->adam_desc, e->n_adam, b4, e4, e->G[2], m, v, e->warena, e->cfg.dtype, lr, beta1, beta2, eps, weight_decay,
+                              bias_corr1, bias_corr2, stream);
 }
 
 extern "C" int klab_engine_set_graph(klab_engine* e, int on) {

@@ -73,10 +73,11 @@ struct AdamDesc { float* p; long goff; long aoff; long n4_prefix; };  // aoff < 
 struct AdamHyper { float lr_over_bc1, beta1, beta2, eps, weight_decay, inv_sqrt_bc2; };
 
 template <typename T>
-__global__ __launch_bounds__(256) void adam_step_kernel(const AdamDesc* __restrict__ d, int nd, long total4, const float* __restrict__ grads,
+__global__ __launch_bounds__(256) void adam_step_kernel(const AdamDesc* __restrict__ d, int nd, long begin4, long total4, const float* __restrict__ grads,
                                                         float* __restrict__ m, float* __restrict__ v, T* __restrict__ arena, AdamHyper h) {
+  // vec4 indices [begin4, total4) of the descriptor table's prefix space (a sub-range = the tensors of one backward segment)
   constexpr int U = 4;
-  for (long g0 = ((long)blockIdx.x * U) * blockDim.x + threadIdx.x; g0 < total4; g0 += (long)gridDim.x * U * blockDim.x) {
+  for (long g0 = begin4 + ((long)blockIdx.x * U) * blockDim.x + threadIdx.x; g0 < total4; g0 += (long)gridDim.x * U * blockDim.x) {
     int lo = 0, hi = nd - 1;
     while (lo < hi) {
       const int mid = (lo + hi + 1) >> 1;
@@ -439,21 +440,29 @@ extern "C" int klab_cast_pack(const void* desc_dev, int ndesc, long total4, void
   return KLAB_OK;
 }
 
-extern "C" int klab_adam_step(const void* desc_dev, int ndesc, long total4, const float* grads, float* m, float* v, void* arena, int dtype,
-                              float lr, float beta1, float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,
-                              void* stream) {
-  if (!desc_dev || ndesc <= 0 || !grads || !m || !v || !arena || bias_corr1 <= 0.f || bias_corr2 <= 0.f) return KLAB_ERR_BADARG;
+extern "C" int klab_adam_step_range(const void* desc_dev, int ndesc, long begin4, long end4, const float* grads, float* m, float* v, void* arena,
+                                    int dtype, float lr, float beta1, float beta2, float eps, float weight_decay, float bias_corr1,
+                                    float bias_corr2, void* stream) {
+  if (!desc_dev || ndesc <= 0 || !grads || !m || !v || !arena || bias_corr1 <= 0.f || bias_corr2 <= 0.f || begin4 < 0 || end4 < begin4)
+    return KLAB_ERR_BADARG;
+  if (end4 == begin4) return KLAB_OK;
   AdamHyper h{lr / bias_corr1, beta1, beta2, eps, weight_decay, 1.f / sqrtf(bias_corr2)};
   hipStream_t s = (hipStream_t)stream;
   static const int cap = [] { const char* e = getenv("KLAB_ADAM_GRID"); return e ? atoi(e) : 1024; }();
-  long gl = ((total4 + 3) / 4 + 255) / 256;
+  long gl = ((end4 - begin4 + 3) / 4 + 255) / 256;
   const unsigned grid = (unsigned)(gl < 1 ? 1 : (gl > cap ? cap : gl));
   if (dtype == KLAB_BF16)
-    hipLaunchKernelGGL(adam_step_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const AdamDesc*)desc_dev, ndesc, total4, grads, m, v, (bf16_t*)arena, h);
+    hipLaunchKernelGGL(adam_step_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const AdamDesc*)desc_dev, ndesc, begin4, end4, grads, m, v, (bf16_t*)arena, h);
   else
-    hipLaunchKernelGGL(adam_step_kernel<float>, dim3(grid), dim3(256), 0, s, (const AdamDesc*)desc_dev, ndesc, total4, grads, m, v, (float*)arena, h);
+    hipLaunchKernelGGL(adam_step_kernel<float>, dim3(grid), dim3(256), 0, s, (const AdamDesc*)desc_dev, ndesc, begin4, end4, grads, m, v, (float*)arena, h);
   KLAB_LAUNCH_CHECK();
   return KLAB_OK;
+}
+extern "C" int klab_adam_step(const void* desc_dev, int ndesc, long total4, const float* grads, float* m, float* v, void* arena, int dtype,
+                              float lr, float beta1, float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,
+                              void* stream) {
+  return klab_adam_step_range(desc_dev, ndesc, 0, total4, grads, m, v, arena, dtype, lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2,
+                              stream);
 }
 
 extern "C" int klab_embed_fwd(const long long* ids, int shift_right, int L, int start_id, int pad_id, const float* table, int vocab,

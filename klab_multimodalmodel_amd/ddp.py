@@ -30,8 +30,12 @@ class SegmentReducer:
         self.max_bucket = max_bucket_elems
         self.comm_stream: Optional[torch.cuda.Stream] = None
         self._works = []
+        self._seg_events = {}  # segment -> event recorded on the comm stream behind that segment's last all-reduce
         backend = dist.get_backend(process_group) if dist.is_initialized() else ""
         self._avg_op = dist.ReduceOp.AVG if backend == "nccl" else None
+
+    def world_active(self):
+        return self.world > 1 or (dist.is_initialized() and os.environ.get("KLAB_DDP_FORCE_COLLECTIVE") == "1")
 
     def buckets(self, seg: int):
         """(model, offset, length) pieces of a segment: large segments are cut so that RCCL can start
@@ -68,6 +72,21 @@ class SegmentReducer:
             else:
                 w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
                 self._works.append((w, t))
+        if self.comm_stream is not None:
+            ev = self._seg_events.get(seg)
+            if ev is None:
+                ev = self._seg_events[seg] = torch.cuda.Event()
+            ev.record(self.comm_stream)
+
+    def finish_segment(self, seg: int, device=None):
+        """partial join: the compute stream may consume segment `seg`'s averaged gradients (later segments may still be in
+        flight).  CPU / gloo groups have no per-segment handle: they join everything."""
+        if self._works:
+            self.finish(device)
+            return
+        ev = self._seg_events.get(seg)
+        if ev is not None and self.comm_stream is not None:
+            torch.cuda.current_stream(device).wait_event(ev)
 
     def finish(self, device=None):
         """join: after this the compute stream may consume the averaged gradients."""
@@ -83,7 +102,12 @@ class DistributedDataParallel(nn.Module):
     """Drop-in for `torch.nn.parallel.DistributedDataParallel(model, device_ids=[...])` around the
     native MyModel (`.module`, `forward(*args)`), with segment-overlapped gradient reduction."""
 
-    def __init__(self, module, device_ids=None, process_group=None, broadcast_parameters=True, max_bucket_elems=64 << 20):
+    def __init__(self, module, device_ids=None, process_group=None, broadcast_parameters=True, max_bucket_elems=64 << 20,
+                 overlap_optimizer=False):
+        """overlap_optimizer=True: backward returns without joining the last all-reduces; `optim.FusedAdam.step()` then
+        updates segment 0 (decoder + embedding) while segment 1 (encoder) is still reducing.  Only for loops whose next
+        consumer of the gradients is FusedAdam (the reference's loop, ref/train.py:62-69); anything else that reads
+        `.grad` first (clipping, logging) must call `ddp.join()` before.  The next forward joins in any case."""
         super().__init__()
         self.module = module
         self.process_group = process_group
@@ -94,6 +118,8 @@ class DistributedDataParallel(nn.Module):
         self._nseg = nseg
         module._direct_grads = True
         module._segment_hook = self._on_segment
+        self.overlap_optimizer = bool(overlap_optimizer)
+        module._pending_reduce = None
         if broadcast_parameters and dist.is_initialized() and dist.get_world_size(process_group) > 1:
             with torch.no_grad():  # torch DDP's _sync_module_states (TORCH/ddp:864-867)
                 for p in module.parameters():
@@ -103,6 +129,15 @@ class DistributedDataParallel(nn.Module):
         flats = {"main": self.module._flat.get("main"), "swin": self.module._flat.get("swin")}
         self.reducer.reduce_segment(seg, flats)
         if seg == self._nseg - 1:
+            if self.overlap_optimizer and self.reducer.world_active():
+                self.module._pending_reduce = self.reducer  # joined per segment by FusedAdam.step / fully by the next forward
+            else:
+                self.reducer.finish()
+
+    def join(self):
+        """wait (stream-wise) for every gradient all-reduce of the last backward"""
+        if self.module._pending_reduce is not None:
+            self.module._pending_reduce = None
             self.reducer.finish()
 
     def forward(self, *args, **kwargs):

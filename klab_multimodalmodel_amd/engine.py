@@ -116,6 +116,8 @@ ENGINE_SIGS = {
     "klab_engine_set_graph": ([C.c_void_p, C.c_int], C.c_int),
     "klab_engine_adam_step": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                C.c_float, C.c_void_p], C.c_int),
+    "klab_engine_adam_step_segment": ([C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                       C.c_float, C.c_float, C.c_void_p], C.c_int),
     "klab_engine_probe_enable": ([C.c_void_p, C.c_int], C.c_int),
     "klab_engine_probe_read": ([C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_double)], C.c_int),
     "klab_engine_loss_ptr": ([C.c_void_p], C.c_void_p),
@@ -329,8 +331,13 @@ class Engine:
         L.check(self._lib.klab_engine_backward(self._h, segment, dloss.data_ptr() if dloss is not None else None, L.stream_ptr()),
                 "klab_engine_backward")
 
-    def adam_step(self, m, v, lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2):
-        """torch.optim.Adam's update for every parameter of the trainable T5 in one kernel (+ refreshed bf16 copies)."""
+    def adam_step(self, m, v, lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, segment=None):
+        """torch.optim.Adam's update for every parameter of the trainable T5 in one kernel (+ refreshed bf16 copies);
+        segment = 0 / 1: only the tensors of that backward segment (both = one full step)."""
+        if segment is not None:
+            L.check(self._lib.klab_engine_adam_step_segment(self._h, int(segment), m.data_ptr(), v.data_ptr(), lr, beta1, beta2, eps,
+                                                            weight_decay, bias_corr1, bias_corr2, L.stream_ptr()), "klab_engine_adam_step_segment")
+            return
         L.check(self._lib.klab_engine_adam_step(self._h, m.data_ptr(), v.data_ptr(), lr, beta1, beta2, eps, weight_decay, bias_corr1,
                                                 bias_corr2, L.stream_ptr()), "klab_engine_adam_step")
 

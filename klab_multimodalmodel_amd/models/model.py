@@ -209,6 +209,7 @@ class MyModel(nn.Module):
         self._views = None
         self._direct_grads = False
         self._segment_hook = None
+        self._pending_reduce = None  # klab DDP(overlap_optimizer=True): reducer whose last all-reduces are not joined yet
         self.use_graph = os.environ.get("KLAB_GRAPH", "0") == "1"  # hipGraph replay of the engine's launch sequences
         self._seed_base = torch.initial_seed() & 0xFFFFFFFF
         self._seed_ctr = 0
@@ -323,6 +324,9 @@ class MyModel(nn.Module):
 
     # ---- the reference surface -----------------------------------------------------------------
     def forward(self, images, source_encoding, target_encoding=None, return_loss=True):
+        if self._pending_reduce is not None:  # nobody consumed the last backward's gradients through FusedAdam: join now
+            red, self._pending_reduce = self._pending_reduce, None
+            red.finish()
         pixels = images["pixel_values"]
         src = source_encoding["input_ids"]
         if pixels.dim() != 4 or pixels.shape[1] != self.swin_cfg.num_channels:

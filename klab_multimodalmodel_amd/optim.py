@@ -70,6 +70,14 @@ class FusedAdam(Optimizer):
                 loss = closure()
         model, why = (None, "fallback already active") if self._fallback is not None else self._fast_ok()
         if model is None:
+            for grp in self.param_groups:  # gradients may still be in flight (klab DDP overlap_optimizer): join before torch reads them
+                for p in grp["params"]:
+                    ref = getattr(p, "_klab_owner", None)
+                    owner = ref() if ref is not None else None
+                    red = getattr(owner, "_pending_reduce", None) if owner is not None else None
+                    if red is not None:
+                        owner._pending_reduce = None
+                        red.finish()
             self._fb_reason = why
             self._step_fallback()
             return loss
@@ -80,8 +88,16 @@ class FusedAdam(Optimizer):
             self._v = torch.zeros_like(flat)
         self._steps += 1
         b1, b2 = g["betas"]
-        model._engine.adam_step(self._m, self._v, float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]),
-                                1.0 - b1 ** self._steps, 1.0 - b2 ** self._steps)
+        hyper = (float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]), 1.0 - b1 ** self._steps, 1.0 - b2 ** self._steps)
+        red = getattr(model, "_pending_reduce", None)
+        if red is not None:  # klab DDP(overlap_optimizer=True): segment 0 is updated while segment 1 is still being reduced
+            model._pending_reduce = None
+            for seg in (0, 1):
+                red.finish_segment(seg)
+                model._engine.adam_step(self._m, self._v, *hyper, segment=seg)
+            red.finish()  # any further segment (Swin) and the bookkeeping
+        else:
+            model._engine.adam_step(self._m, self._v, *hyper)
         model._note_optimizer_step()
         self._owner = weakref.ref(model)
         return loss

@@ -175,7 +175,7 @@ def test_full_size_architecture_matches_oracle(dtype, loss_tol, cos_min):
     assert c > cos_min
 
 
-def _train_steps(wrap, accumulate=1, steps=3, fused_adam=False):
+def _train_steps(wrap, accumulate=1, steps=3, fused_adam=False, overlap=False):
     """the reference's loop body (ref/train.py:58-71) on a tiny config; returns losses and final weights."""
     import torch.distributed as dist
     m, g = build("tiny_b", torch.float32, True)
@@ -185,7 +185,7 @@ def _train_steps(wrap, accumulate=1, steps=3, fused_adam=False):
         core = model.module
     elif wrap == "klab":
         from klab_multimodalmodel_amd.ddp import DistributedDataParallel
-        model = DistributedDataParallel(m, device_ids=[0])
+        model = DistributedDataParallel(m, device_ids=[0], overlap_optimizer=overlap)
         core = model.module
     else:
         model = core = m
@@ -200,6 +200,8 @@ def _train_steps(wrap, accumulate=1, steps=3, fused_adam=False):
         losses.append(loss.item())
         (loss / accumulate).backward()
         if (i + 1) % accumulate == 0:
+            if overlap and not fused_adam:
+                model.join()  # a consumer other than FusedAdam has to join the pending all-reduces itself
             opt.step()
             opt.zero_grad()
     w = {k: v.detach().clone() for k, v in core.transformer.state_dict().items()}
@@ -224,11 +226,17 @@ def test_reference_training_loop_under_stock_ddp_and_klab_ddp():
             os.environ["KLAB_DDP_FORCE_COLLECTIVE"] = "1"  # same, with the RCCL all-reduces really issued on the comm stream
             try:
                 l4, w4, _s4 = _train_steps("klab", acc, fused_adam=True)
+                # overlap_optimizer: backward leaves the last all-reduces unjoined, FusedAdam updates segment by segment
+                l5, w5, _s5 = _train_steps("klab", acc, fused_adam=True, overlap=True)
+                l6, w6, _s6 = _train_steps("klab", acc, fused_adam=False, overlap=True)  # torch Adam behind an explicit ddp.join()
             finally:
                 del os.environ["KLAB_DDP_FORCE_COLLECTIVE"]
             assert max(abs(x - y) for x, y in zip(l0, l4)) < 2e-4, (acc, l0, l4)
+            assert max(abs(x - y) for x, y in zip(l0, l5)) < 2e-4, (acc, l0, l5)
+            assert max(abs(x - y) for x, y in zip(l0, l6)) < 2e-4, (acc, l0, l6)
             for k in w0:
                 assert rel_l2(w4[k].cpu(), w0[k].cpu()) < 2e-3, k
+                assert rel_l2(w5[k].cpu(), w0[k].cpu()) < 2e-3, k
             assert max(abs(x - y) for x, y in zip(l0, l3)) < 2e-4, (acc, l0, l3)
             for k in w0:
                 assert rel_l2(w3[k].cpu(), w0[k].cpu()) < 2e-3, k
