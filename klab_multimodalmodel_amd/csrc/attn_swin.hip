@@ -9,8 +9,10 @@
 //   one wave per (image, window, head); keys/values of the window live in LDS (k pre-normalised);
 //   lane i owns query row i (rows i, i+64, ... when n > 64): q-hat and the output row stay in
 //   registers, softmax is online (running max / sum per lane) -- no cross-lane traffic at all.
-// Round-1 form: fp32 vector-ALU dot products (n = 49, hd = 32 tiles are awkward MFMA shapes; the
-// padded-to-64 MFMA form is the planned replacement, SURVEY §7 "small-tile efficiency").
+// This first kernel is the generic form (fp32 and any head dim: vector-ALU dot products); bf16 with head dim 32 and
+// windows of <= 64 tokens -- every standard Swin-V2 -- runs on the matrix cores instead: swin_attn_fwd_mfma32 /
+// swin_qkv_attn_fused below (49-token windows padded to 64) and, backward, the gather -> t5_attn_bwd_mfma<32> -> scatter
+// sequence of swin_attn_bwd_mfma.
 #include <math.h>
 #include <string.h>
 
