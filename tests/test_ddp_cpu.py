@@ -39,6 +39,14 @@ def _worker(rank, world, port, q):
         # a model with no swin gradients (frozen): the reducer skips the missing buffer
         red.reduce_segment(2, {"main": flats["main"], "swin": None})
         red.finish()
+        # per-segment join (DDP overlap_optimizer): on a backend without a comm stream it degrades to the full join
+        f2 = {"main": torch.arange(1500, dtype=torch.float32) * (rank + 1), "swin": None}
+        red.reduce_segment(0, f2)
+        red.reduce_segment(1, f2)
+        red.finish_segment(0)
+        ok = ok and torch.allclose(f2["main"], base * (sum(range(1, world + 1)) / world)) and red.world_active()
+        red.finish_segment(1)
+        red.finish()
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
