@@ -284,6 +284,11 @@ int klab_engine_set_graph(klab_engine* e, int on);
  * told (training bit 2) that they are current. */
 int klab_engine_adam_step(klab_engine* e, float* m, float* v, float lr, float beta1, float beta2, float eps, float weight_decay,
                           float bias_corr1, float bias_corr2, void* stream);
+/* Pipelining of the optimizer step with the next forward: hip_event (hipEvent_t, caller-owned, must stay alive until that forward
+ * has been enqueued) marks the end of an optimizer step the caller launched on ANOTHER stream.  The next klab_engine_forward
+ * starts the frozen towers at once and waits for the event only in front of the first kernel that reads a trainable tensor
+ * (or at its very start when it has to re-cast the masters, replays a graph or re-enters decoder-only).  One-shot; NULL clears. */
+int klab_engine_set_weight_event(klab_engine* e, void* hip_event);
 /* the kernel behind it: desc = device array of {float* p; long grad_off; long arena_off (<0: none); long n4_prefix} */
 int klab_adam_step(const void* desc_dev, int ndesc, long total4, const float* grads, float* m, float* v, void* arena, int dtype, float lr,
                    float beta1, float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, void* stream);

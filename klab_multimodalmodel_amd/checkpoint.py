@@ -72,6 +72,10 @@ class AsyncCheckpointer:
         self.wait()  # one save in flight: the pinned snapshot of the previous one is released first
         core = _core(model)
         dev = next(core.transformer.parameters()).device
+        if hasattr(core, "_join_weights"):
+            core._join_weights()  # an update running on the optimizer's own stream (FusedAdam overlap_next_forward)
+        if optimizer is not None and hasattr(optimizer, "join"):
+            optimizer.join()
         stream = None
         if dev.type == "cuda":
             if self._stream is None:

@@ -98,7 +98,8 @@ struct klab_engine {
   float* G[3] = {nullptr, nullptr, nullptr};
   void* warena = nullptr; float* farena = nullptr;
   void* cast_desc = nullptr; int n_cast = 0; long cast_total4 = 0;      // trainable GEMM weights (cast every forward)
-  void* adam_desc = nullptr; int n_adam = 0; long adam_total4 = 0, adam_split4 = 0;        // fused optimizer step over the trainable T5 (f-2)
+  void* adam_desc = nullptr; int n_adam = 0; long adam_total4 = 0, adam_split4 = 0;
+  hipEvent_t weights_ev = nullptr; bool weights_ev_defer = false;        // optimizer step still running on another stream (klab_engine_set_weight_event)        // fused optimizer step over the trainable T5 (f-2)
   // RMS-norm weight gradients of a stack: per-workgroup partials of every norm, folded by one reduction per stack
   float* rms_part = nullptr; long rms_part_stride = 0; float** rms_dst_dev[2] = {nullptr, nullptr}; int rms_ncalls[2] = {0, 0};
   void* cast_desc_frozen = nullptr; int n_cast_frozen = 0; long cast_total4_frozen = 0;  // frozen towers (cast when dirty)
@@ -1164,6 +1165,10 @@ int forward_part_a(klab_engine* e, hipStream_t stream, float p, bool refresh_fro
     RC((int)hipEventRecord(e->ev_join, e->side));
   }
   RC((int)hipStreamWaitEvent(c.s, e->ev_join, 0));
+  if (e->weights_ev && e->weights_ev_defer) {  // the optimizer step of the previous iteration ran beside the frozen towers
+    RC((int)hipStreamWaitEvent(c.s, e->weights_ev, 0));
+    e->weights_ev = nullptr;
+  }
   // 4. T5 encoder (HF/t5:1009-1016)
   RC(t5_stack_forward(c, cfg.main, e->P[2], e->W[2], e->mi.enc, e->mi.enc_final, e->enc, false, STACK_ENC, p, B, nullptr, 0, 0, nullptr, 0, 0, 0,
                       p));
@@ -1196,6 +1201,12 @@ extern "C" int klab_engine_adam_step_segment(klab_engine* e, int segment, float*
   const long b4 = segment == 0 ? 0 : e->adam_split4, e4 = segment == 0 ? e->adam_split4 : e->adam_total4;
   return klab_adam_step_range(e->adam_desc, e->n_adam, b4, e4, e->G[2], m, v, e->warena, e->cfg.dtype, lr, beta1, beta2, eps, weight_decay,
                               bias_corr1, bias_corr2, stream);
+}
+
+extern "C" int klab_engine_set_weight_event(klab_engine* e, void* hip_event) {
+  if (!e) return KLAB_ERR_BADARG;
+  e->weights_ev = (hipEvent_t)hip_event;
+  return KLAB_OK;
 }
 
 extern "C" int klab_engine_set_graph(klab_engine* e, int on) {
@@ -1239,6 +1250,12 @@ extern "C" int klab_engine_forward(klab_engine* e, const float* pixels, const lo
   // bit 3: same images, prompt and weights as the previous forward of this binding, evaluation mode: only the decoder and the
   // LM head run (greedy decoding, ref/models/model.py:28).  Ignored under graph replay and whenever gradients are wanted.
   const bool ecur = (training & 8) && !(training & 1) && !want_grad && !e->use_graph && e->frozen_valid && !refresh_frozen;
+  if (e->weights_ev) {
+    // trainable weights are still being written on another stream: the frozen towers may start, the first kernel that reads a
+    // trainable tensor waits (forward_part_a); every other situation (cast of the masters, graph replay, decoder-only re-entry) waits now
+    e->weights_ev_defer = tcur && !ecur && !e->use_graph;
+    if (!e->weights_ev_defer) { RC((int)hipStreamWaitEvent(c.s, e->weights_ev, 0)); e->weights_ev = nullptr; }
+  }
   if (refresh_frozen) {  // not worth a graph slot: happens once per weight version
     RC(forward_part_a(e, c.s, p, true, tcur));
     e->frozen_valid = true;

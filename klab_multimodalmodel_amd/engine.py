@@ -118,6 +118,7 @@ ENGINE_SIGS = {
                                C.c_float, C.c_void_p], C.c_int),
     "klab_engine_adam_step_segment": ([C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                        C.c_float, C.c_float, C.c_void_p], C.c_int),
+    "klab_engine_set_weight_event": ([C.c_void_p, C.c_void_p], C.c_int),
     "klab_engine_probe_enable": ([C.c_void_p, C.c_int], C.c_int),
     "klab_engine_probe_read": ([C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_double)], C.c_int),
     "klab_engine_loss_ptr": ([C.c_void_p], C.c_void_p),
@@ -340,6 +341,11 @@ class Engine:
             return
         L.check(self._lib.klab_engine_adam_step(self._h, m.data_ptr(), v.data_ptr(), lr, beta1, beta2, eps, weight_decay, bias_corr1,
                                                 bias_corr2, L.stream_ptr()), "klab_engine_adam_step")
+
+    def set_weight_event(self, event):
+        """`event` (torch.cuda.Event recorded behind an optimizer step on another stream, or None): the next forward waits for it
+        only in front of its first use of a trainable tensor.  The caller keeps the event alive until that forward is enqueued."""
+        L.check(self._lib.klab_engine_set_weight_event(self._h, None if event is None else event.cuda_event), "klab_engine_set_weight_event")
 
     def set_graph(self, on=True):
         """replay the launch sequences as hipGraphs (inputs are staged, so any input tensors may be passed)."""

@@ -175,7 +175,7 @@ def test_full_size_architecture_matches_oracle(dtype, loss_tol, cos_min):
     assert c > cos_min
 
 
-def _train_steps(wrap, accumulate=1, steps=3, fused_adam=False, overlap=False):
+def _train_steps(wrap, accumulate=1, steps=3, fused_adam=False, overlap=False, adam_overlap=False):
     """the reference's loop body (ref/train.py:58-71) on a tiny config; returns losses and final weights."""
     import torch.distributed as dist
     m, g = build("tiny_b", torch.float32, True)
@@ -191,7 +191,7 @@ def _train_steps(wrap, accumulate=1, steps=3, fused_adam=False, overlap=False):
         model = core = m
     if fused_adam:
         from klab_multimodalmodel_amd.optim import FusedAdam
-        opt = FusedAdam(core.transformer.parameters(), lr=1e-3)
+        opt = FusedAdam(core.transformer.parameters(), lr=1e-3, overlap_next_forward=adam_overlap)
     else:
         opt = torch.optim.Adam(core.transformer.parameters(), lr=1e-3)
     losses = []
@@ -204,6 +204,8 @@ def _train_steps(wrap, accumulate=1, steps=3, fused_adam=False, overlap=False):
                 model.join()  # a consumer other than FusedAdam has to join the pending all-reduces itself
             opt.step()
             opt.zero_grad()
+    if adam_overlap:
+        opt.join()  # parameters are read directly below
     w = {k: v.detach().clone() for k, v in core.transformer.state_dict().items()}
     sg = core.image_model.get_parameter("layernorm.weight").grad
     return losses, w, None if sg is None else sg.detach().clone()
@@ -228,12 +230,17 @@ def test_reference_training_loop_under_stock_ddp_and_klab_ddp():
                 l4, w4, _s4 = _train_steps("klab", acc, fused_adam=True)
                 # overlap_optimizer: backward leaves the last all-reduces unjoined, FusedAdam updates segment by segment
                 l5, w5, _s5 = _train_steps("klab", acc, fused_adam=True, overlap=True)
+                # ... and with the update on its own stream beside the next forward's frozen towers (what bench.py runs at N > 1)
+                l7, w7, _s7 = _train_steps("klab", acc, fused_adam=True, overlap=True, adam_overlap=True)
                 l6, w6, _s6 = _train_steps("klab", acc, fused_adam=False, overlap=True)  # torch Adam behind an explicit ddp.join()
             finally:
                 del os.environ["KLAB_DDP_FORCE_COLLECTIVE"]
             assert max(abs(x - y) for x, y in zip(l0, l4)) < 2e-4, (acc, l0, l4)
             assert max(abs(x - y) for x, y in zip(l0, l5)) < 2e-4, (acc, l0, l5)
             assert max(abs(x - y) for x, y in zip(l0, l6)) < 2e-4, (acc, l0, l6)
+            assert max(abs(x - y) for x, y in zip(l0, l7)) < 2e-4, (acc, l0, l7)
+            for k in w0:
+                assert rel_l2(w7[k].cpu(), w0[k].cpu()) < 2e-3, k
             for k in w0:
                 assert rel_l2(w4[k].cpu(), w0[k].cpu()) < 2e-3, k
                 assert rel_l2(w5[k].cpu(), w0[k].cpu()) < 2e-3, k
@@ -327,8 +334,8 @@ def test_frozen_tower_caches_follow_weight_updates():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("wd", [0.0, 0.01])
-def test_fused_adam_matches_torch_adam(dtype, wd):
+@pytest.mark.parametrize("wd,overlap", [(0.0, False), (0.01, False), (0.01, True)])
+def test_fused_adam_matches_torch_adam(dtype, wd, overlap):
     """optim.FusedAdam (one kernel over the flat buffers, bf16 copies refreshed, forward's cast skipped) follows
     torch.optim.Adam (ref/train.py:28) step for step: same parameters after 4 steps in eval mode (no dropout noise)."""
     from klab_multimodalmodel_amd.optim import FusedAdam
@@ -338,7 +345,8 @@ def test_fused_adam_matches_torch_adam(dtype, wd):
         m._direct_grads = True
         m.transformer.eval()
         ps = list(m.transformer.parameters())
-        opts.append(FusedAdam(ps, lr=3e-3, weight_decay=wd) if fused else torch.optim.Adam(ps, lr=3e-3, weight_decay=wd))
+        # overlap: the update runs on its own stream beside the next forward's frozen towers (overlap_next_forward)
+        opts.append(FusedAdam(ps, lr=3e-3, weight_decay=wd, overlap_next_forward=overlap) if fused else torch.optim.Adam(ps, lr=3e-3, weight_decay=wd))
         ms.append(m)
     losses = [[], []]
     for step in range(4):
@@ -349,6 +357,7 @@ def test_fused_adam_matches_torch_adam(dtype, wd):
             opts[k].zero_grad()
             losses[k].append(float(loss))
     assert opts[1]._fallback is None, opts[1]._fb_reason          # the one-kernel path really ran
+    opts[1].join()                                                 # (overlap: parameters are read directly below)
     assert ms[1]._trainable_current()                              # ... and the next forward would skip its cast
     tol = 2e-5 if dtype == torch.float32 else 2e-3                 # bf16: both sides see bf16-rounded gradients of slightly different weights
     for a, b in zip(losses[0], losses[1]):
