@@ -453,29 +453,17 @@ __global__ __launch_bounds__(256) void t5_attn_bwd_mfma(AttnMP p) {
 // dbias[h,q,k] += sum_b dS[b,h,q,k].  gridDim.y == 1: fixed order, bit-reproducible; gridDim.y > 1 (many slabs, e.g. all
 // layers of a stack at once): each y reduces a contiguous chunk of slabs and adds its partial with one f32 atomic.
 __global__ __launch_bounds__(256) void dbias_reduce_kernel(const bf16_t* __restrict__ ds, float* __restrict__ dbias, int B, int HLq, int Lk, int Lkp) {
-  // a thread owns 8 consecutive keys of one (head, query) row: one 16-byte load per slab (rows are Lkp = 32 j bf16 long)
-  const int cpr = Lkp >> 3;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)HLq * cpr) return;
-  const long row = idx / cpr;
-  const int k0 = (int)(idx % cpr) * 8;
-  if (k0 >= Lk) return;
+  if (idx >= (long)HLq * Lk) return;
+  const long row = idx / Lk;
+  const int k = idx % Lk;
   const int per = (B + gridDim.y - 1) / gridDim.y;
   const int b0 = blockIdx.y * per, b1 = b0 + per < B ? b0 + per : B;
-  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-  for (int b = b0; b < b1; ++b) {  // independent loads: keep many in flight
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(ds + ((long)b * HLq + row) * Lkp + k0);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) a[u] += (float)v[u];
-  }
-  float* out = dbias + row * Lk + k0;
-#pragma unroll
-  for (int u = 0; u < 8; ++u)
-    if (k0 + u < Lk) {
-      if (gridDim.y == 1) out[u] += a[u];
-      else if (b1 > b0) atomicAdd(out + u, a[u]);
-    }
+  float a = 0.f;
+#pragma unroll 16
+  for (int b = b0; b < b1; ++b) a += (float)ds[((long)b * HLq + row) * Lkp + k];  // independent loads: keep many in flight
+  if (gridDim.y == 1) dbias[idx] += a;
+  else if (b1 > b0) atomicAdd(dbias + idx, a);
 }
 
 template <typename K>
@@ -511,7 +499,7 @@ static int launch_bwd(const AttnMP& p, hipStream_t s) {
   hipLaunchKernelGGL((t5_attn_bwd_mfma<DK>), dim3(p.B * p.H), dim3(256), lds, s, p);
   KLAB_LAUNCH_CHECK();
   if (p.dbias && p.ds_ws && !p.defer_reduce) {
-    const long tot = (long)p.H * p.Lq * (Lkp / 8);
+    const long tot = (long)p.H * p.Lq * p.Lk;
     hipLaunchKernelGGL(dbias_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, p.ds_ws, p.dbias, p.B, p.H * p.Lq, p.Lk, Lkp);
     KLAB_LAUNCH_CHECK();
   }
@@ -559,7 +547,7 @@ int t5_attn_bwd_mfma_dispatch(const klab_attn_args* a, hipStream_t s) {
 
 int dbias_reduce_dispatch(const void* ds_ws, float* dbias, int nbatch, int H, int Lq, int Lk, hipStream_t s) {
   const int Lkp = (Lk + 31) & ~31;
-  const long tot = (long)H * Lq * (Lkp / 8);
+  const long tot = (long)H * Lq * Lk;
   int gy = nbatch / 16;  // >= 16 slabs per chunk
   gy = gy < 1 ? 1 : (gy > 32 ? 32 : gy);
   if (nbatch <= 64) gy = 1;
