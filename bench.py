@@ -139,7 +139,7 @@ def main():
     core.use_graph = bool(a.graph)  # forward / backward launch sequences replayed as hipGraphs (same kernels, same math)
     if a.optimizer == "klab":  # torch.optim.Adam's update rule in one kernel over the flat buffers (+ bf16 weight copies)
         from klab_multimodalmodel_amd.optim import FusedAdam
-        optimizer = FusedAdam(core.transformer.parameters(), lr=1e-3, overlap_next_forward=os.environ.get("KLAB_BENCH_OVERLAP_ADAM", "0") == "1")  # opt-in: +0.7 % at N=1, but 2x SLOWER in the one-rank DDP rehearsal
+        optimizer = FusedAdam(core.transformer.parameters(), lr=1e-3)
     else:                      # ref/train.py:28 verbatim (torch's own fused multi-tensor kernel)
         optimizer = torch.optim.Adam(core.transformer.parameters(), lr=1e-3, fused=True)
     core.transformer.train()                                               # ref/train.py:52

@@ -278,17 +278,16 @@ int klab_engine_forward(klab_engine* e, const float* pixels, const long long* sr
 /* hipGraph replay of the forward / backward launch sequences (first use eager, second captured, then replayed;
  * inputs are staged into engine-owned buffers so node addresses stay fixed).  Off by default.          */
 int klab_engine_set_graph(klab_engine* e, int on);
+/* dropout RNG state of the binding (base seed, forwards since seeding): saved / restored by a true resume so that the run
+ * continues its mask stream.  get synchronises `stream`.                                                                  */
+int klab_engine_get_rng(klab_engine* e, uint32_t* base, uint32_t* counter, void* stream);
+int klab_engine_set_rng(klab_engine* e, uint32_t base, uint32_t counter, void* stream);
 /* torch.optim.Adam's update (ref/train.py:28; no amsgrad, L2 weight decay) for ALL parameters of the
  * trainable T5 in one pass.  m / v: caller-owned f32 state laid out like the "main" flat gradient buffer.  bias_corr{1,2} =
  * 1 - beta^step.  Also refreshes the compute-dtype copies of the GEMM weights, so the next klab_engine_forward may be
  * told (training bit 2) that they are current. */
 int klab_engine_adam_step(klab_engine* e, float* m, float* v, float lr, float beta1, float beta2, float eps, float weight_decay,
                           float bias_corr1, float bias_corr2, void* stream);
-/* Pipelining of the optimizer step with the next forward: hip_event (hipEvent_t, caller-owned, must stay alive until that forward
- * has been enqueued) marks the end of an optimizer step the caller launched on ANOTHER stream.  The next klab_engine_forward
- * starts the frozen towers at once and waits for the event only in front of the first kernel that reads a trainable tensor
- * (or at its very start when it has to re-cast the masters, replays a graph or re-enters decoder-only).  One-shot; NULL clears. */
-int klab_engine_set_weight_event(klab_engine* e, void* hip_event);
 /* the kernel behind it: desc = device array of {float* p; long grad_off; long arena_off (<0: none); long n4_prefix} */
 int klab_adam_step(const void* desc_dev, int ndesc, long total4, const float* grads, float* m, float* v, void* arena, int dtype, float lr,
                    float beta1, float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, void* stream);
@@ -309,7 +308,16 @@ int klab_engine_probe_enable(klab_engine* e, int on);
 int klab_engine_probe_read(klab_engine* e, int* launches, float* total_ms, double* flops_per_launch);
 const float* klab_engine_loss_ptr(const klab_engine* e);
 const int* klab_engine_err_ptr(const klab_engine* e);
+/* device words {seed of the current step, base seed, forwards since seeding} (for stream-ordered snapshots; see klab_engine_get_rng) */
+const uint32_t* klab_engine_rng_ptr(const klab_engine* e);
 const void* klab_engine_buffer(const klab_engine* e, const char* name, long* rows, long* cols, int* dtype);
+
+/* ---- crash diagnostics (opt-in; csrc/diag.cpp) -------------------------------------------------------------------------
+ * klab_segv_trace_install: on SIGSEGV / SIGBUS / SIGABRT / SIGFPE / SIGILL write the context string and the native backtrace
+ * of the faulting thread to file descriptor fd (< 0: stderr), then re-raise with the default action.
+ * klab_segv_set_context: the string to print (the test harness passes the running pytest node id).                       */
+int klab_segv_trace_install(int fd);
+int klab_segv_set_context(const char* text);
 
 #ifdef __cplusplus
 }

@@ -82,6 +82,8 @@ SIGNATURES = {
     "klab_convert": [vp, vp, i32, i64, f32, vp],
     "klab_add_f32": [vp, vp, i64, vp],
     "klab_image_preprocess_ws_bytes": [i32, i32, i32],
+    "klab_segv_trace_install": [i32],
+    "klab_segv_set_context": [C.c_char_p],
     "klab_image_preprocess": [vp, vp, i32, i32, i32, i32, i32, i32, i32, C.c_double, vp, vp, vp, vp, C.c_size_t, vp],
 }
 

@@ -58,12 +58,14 @@ class AsyncCheckpointer:
         self._thread = None
         self._error = None
         self._stream = None
+        self._hold = None
 
     def wait(self):
         """block until the last save is on disk; re-raises its error, if any"""
         if self._thread is not None:
             self._thread.join()
             self._thread = None
+        self._hold = None  # pinned snapshot buffers are released here, on the caller's thread (not by the writer thread)
         if self._error is not None:
             e, self._error = self._error, None
             raise e
@@ -72,32 +74,40 @@ class AsyncCheckpointer:
         self.wait()  # one save in flight: the pinned snapshot of the previous one is released first
         core = _core(model)
         dev = next(core.transformer.parameters()).device
-        if hasattr(core, "_join_weights"):
-            core._join_weights()  # an update running on the optimizer's own stream (FusedAdam overlap_next_forward)
-        if optimizer is not None and hasattr(optimizer, "join"):
-            optimizer.join()
+        # 1. everything that creates tensors on the CURRENT stream first (FusedAdam.state_dict() clones its moments, other
+        #    optimizers may build theirs lazily) ...
+        flat = _flat_state(optimizer) if optimizer is not None else None
+        t_sd = core.transformer.state_dict() if rank == 0 else None
+        i_sd = core.image_model.state_dict() if rank == 0 and getattr(core.args, "image_model_train", False) else None
+        o_sd = optimizer.state_dict() if rank == 0 and optimizer is not None and flat is None else None
+        eng = getattr(core, "_engine", None)
+        rng_dev = eng.rng_view if rank == 0 and eng is not None and getattr(eng, "shape", None) is not None else None
+        # 2. ... then the side stream waits for the current one: the snapshot sees every update and every temporary above
         stream = None
         if dev.type == "cuda":
             if self._stream is None:
                 self._stream = torch.cuda.Stream(device=dev)
             stream = self._stream
-            stream.wait_stream(torch.cuda.current_stream(dev))  # the snapshot sees every update enqueued so far
+            stream.wait_stream(torch.cuda.current_stream(dev))
         payload, shard = None, None
-        flat = _flat_state(optimizer) if optimizer is not None else None
         if rank == 0:
-            payload = {"transformer": _to_host(core.transformer.state_dict(), stream)}  # ref/models/model.py:32
-            if getattr(core.args, "image_model_train", False):
-                payload["image_model"] = _to_host(core.image_model.state_dict(), stream)  # :33-34
+            payload = {"transformer": _to_host(t_sd, stream)}  # ref/models/model.py:32
+            if i_sd is not None:
+                payload["image_model"] = _to_host(i_sd, stream)  # :33-34
             payload["step"] = int(step)
             payload["world"] = int(world)
             payload["rng"] = {"cpu": torch.get_rng_state(), "cuda": torch.cuda.get_rng_state(dev) if dev.type == "cuda" else None}
+            # the engine's device-side dropout RNG {step seed, base, forwards since seeding} + the model's base seed: a resumed
+            # run continues the mask stream instead of replaying the masks of steps 1..k
+            payload["engine_rng"] = {"seed_base": int(getattr(core, "_seed_base", 0)),
+                                     "state": _to_host(rng_dev, stream) if rng_dev is not None else None}
             if scheduler is not None:
                 payload["scheduler"] = scheduler.state_dict()
             if extra is not None:
                 payload["extra"] = extra
             if optimizer is not None:
                 if flat is None:
-                    payload["optimizer"] = _to_host(optimizer.state_dict(), stream)
+                    payload["optimizer"] = _to_host(o_sd, stream)
                 else:
                     payload["optimizer_flat"] = {"numel": flat[0].numel(), "steps": int(flat[2]), "shards": int(world),
                                                  "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in optimizer.param_groups]}
@@ -105,6 +115,7 @@ class AsyncCheckpointer:
             n = flat[0].numel()
             lo, hi = n * rank // world, n * (rank + 1) // world
             shard = {"lo": lo, "hi": hi, "exp_avg": _to_host(flat[0][lo:hi], stream), "exp_avg_sq": _to_host(flat[1][lo:hi], stream)}
+        keep = (t_sd, i_sd, o_sd, rng_dev)  # device temporaries stay referenced until the copy event has completed (write())
         ev = None
         if stream is not None:
             ev = torch.cuda.Event()
@@ -113,9 +124,11 @@ class AsyncCheckpointer:
         path = os.path.join(self.dir, name)
 
         def write():
+            nonlocal keep
             try:
                 if ev is not None:
                     ev.synchronize()
+                keep = None  # the device-side sources may go now
                 for obj, p in ((payload, path), (shard, f"{path}.opt{rank}of{world}")):
                     if obj is not None:
                         torch.save(obj, p + ".tmp")
@@ -123,6 +136,7 @@ class AsyncCheckpointer:
             except BaseException as e:  # surfaced by wait()
                 self._error = e
 
+        self._hold = (payload, shard)
         self._thread = threading.Thread(target=write, name="klab-checkpoint", daemon=False)
         self._thread.start()
         return path
@@ -160,6 +174,16 @@ def load_checkpoint(path, model, optimizer=None, scheduler=None, restore_rng=Fal
                 g.update(saved)
     if scheduler is not None and "scheduler" in ck:
         scheduler.load_state_dict(ck["scheduler"])
+    er = ck.get("engine_rng")
+    if er is not None and hasattr(core, "_seed_base"):  # continue the dropout mask stream (always: it is part of the training state)
+        core._seed_base = int(er["seed_base"])
+        if er.get("state") is not None:
+            st = [int(x) & 0xFFFFFFFF for x in er["state"].tolist()]
+            eng = core._engine
+            if getattr(eng, "shape", None) is not None and core._bound_key is not None:
+                eng.set_rng(st[1], st[2])
+            else:
+                core._pending_rng = (st[1], st[2])
     if restore_rng and "rng" in ck:
         torch.set_rng_state(ck["rng"]["cpu"])
         if ck["rng"]["cuda"] is not None and torch.cuda.is_available():

@@ -90,6 +90,7 @@ struct klab_engine {
   long seg_off[3] = {0, 0, 0}, seg_len[3] = {0, 0, 0};            // per segment: extent in its flat grad buffer
   long warena_elems = 0, farena_elems = 0;
   long kvall_w_off = -1, kvall_g_off = -1;  // decoder cross k|v of all layers (weight arena / grad offsets)
+  int pe_k0 = 0, pe_kp = 0;  // patch-embedding weight rows: K0 = in_ch*patch^2 values, stored at a pitch of pe_kp (zero-padded)
   // ---- bound state ----
   bool bound = false;
   int B = 0, Ls = 0, Lt = 0, Le = 0, Nimg = 0;
@@ -99,7 +100,6 @@ struct klab_engine {
   void* warena = nullptr; float* farena = nullptr;
   void* cast_desc = nullptr; int n_cast = 0; long cast_total4 = 0;      // trainable GEMM weights (cast every forward)
   void* adam_desc = nullptr; int n_adam = 0; long adam_total4 = 0, adam_split4 = 0;
-  hipEvent_t weights_ev = nullptr; bool weights_ev_defer = false;        // optimizer step still running on another stream (klab_engine_set_weight_event)        // fused optimizer step over the trainable T5 (f-2)
   // RMS-norm weight gradients of a stack: per-workgroup partials of every norm, folded by one reduction per stack
   float* rms_part = nullptr; long rms_part_stride = 0; float** rms_dst_dev[2] = {nullptr, nullptr}; int rms_ncalls[2] = {0, 0};
   void* cast_desc_frozen = nullptr; int n_cast_frozen = 0; long cast_total4_frozen = 0;  // frozen towers (cast when dirty)
@@ -267,7 +267,14 @@ void plan_arenas(klab_engine* e) {
   }
   {
     auto& v = e->P[0];
-    putw(v, e->si.pew);
+    {  // patch-embedding weight [C0, K0]: bf16 rows are stored at a pitch of K0 rounded up to 32 with zero padding, so that
+       // the LDS-DMA GEMM (K % 32 == 0) never reads past a row
+      const klab_swin_cfg& sc = e->cfg.swin;
+      e->pe_k0 = sc.in_ch * sc.patch * sc.patch;
+      e->pe_kp = (e->cfg.dtype == KLAB_BF16 && sc.patch == 4) ? ((e->pe_k0 + 31) & ~31) : e->pe_k0;
+      v[e->si.pew].warena_off = w;
+      w += pad8((long)sc.embed_dim * e->pe_kp);
+    }
     for (auto& st : e->si.st) {
       for (auto& k : st.blk) {
         putw(v, k.qw); putw(v, k.kw); putw(v, k.vw); putw(v, k.pw); putw(v, k.f1w); putw(v, k.f2w);
@@ -393,9 +400,10 @@ size_t plan_workspace(klab_engine* e, void* base, int B, int Ls, int Lt) {
   e->pixels_buf = (float*)b.take((size_t)B * c.swin.in_ch * c.swin.image_size * c.swin.image_size * 4);
   e->src_buf = (long long*)b.take((size_t)B * Ls * 8);
   e->tgt_buf = (long long*)b.take((size_t)B * Lt * 8);
-  e->warena = b.take((size_t)(e->warena_elems + 64) * es);  // + slack: the patch-embedding GEMM reads K padded to 32 past a weight row
+  e->warena = b.take((size_t)e->warena_elems * es);
   e->farena = (float*)b.take((size_t)e->farena_elems * 4);
-  e->cast_desc = b.take(sizeof(long) * 3 * 2 * (e->P[0].size() + e->P[1].size() + e->P[2].size() + 1));  // two groups
+  // two descriptor groups (trainable / frozen); the patch-embedding weight contributes one descriptor per row
+  e->cast_desc = b.take(sizeof(long) * 3 * 2 * (e->P[0].size() + e->P[1].size() + e->P[2].size() + c.swin.embed_dim + 1));
   e->fcast_desc = b.take(sizeof(long) * 3 * (e->P[0].size() + 1));
   e->adam_desc = b.take(sizeof(long) * 4 * (e->P[2].size() + 1));
   {
@@ -790,13 +798,13 @@ int swin_forward(const Ctx& c, const float* pixels, float p_in, bool refresh_bia
   const auto& W = e->W[0];
   const int B = e->B, R0 = s.image_size / s.patch, K0 = s.in_ch * s.patch * s.patch, C0 = s.embed_dim;
   const long M0 = (long)B * R0 * R0;
-  // patch embedding (Conv2d k4 s4, HF/swinv2:281) = im2col + GEMM.  bf16: the rows are zero-padded from K0 = 48 to 64
-  // columns so that the GEMM takes the LDS-DMA path (K % 32 == 0); the weight rows keep their pitch of K0, the 16 extra
-  // columns read there are the next row's (finite) weights and meet zeros.
-  const int Kp = (c.dt == KLAB_BF16 && s.patch == 4) ? ((K0 + 31) & ~31) : K0;
+  // patch embedding (Conv2d k4 s4, HF/swinv2:281) = im2col + GEMM.  bf16: both operands' rows are zero-padded from K0 = 48
+  // to 64 columns so that the GEMM takes the LDS-DMA path (K % 32 == 0); zeros meet zeros.
+  const int Kp = e->pe_kp;
+  (void)K0;
   RC(klab_im2col_patch_ld(pixels, e->cols, c.dt, B, s.in_ch, s.image_size, s.patch, Kp, c.ws()));
   {
-    klab_gemm_args g = G0(c, (int)M0, C0, Kp, e->cols, Kp, 1, woff(c, P[e->si.pew].warena_off), K0, 1, e->pe_out, C0, c.dt);
+    klab_gemm_args g = G0(c, (int)M0, C0, Kp, e->cols, Kp, 1, woff(c, P[e->si.pew].warena_off), Kp, 1, e->pe_out, C0, c.dt);
     g.bias = W[e->si.peb];
     RC(klab_gemm(&g, c.ws()));
   }
@@ -902,18 +910,28 @@ extern "C" klab_engine* klab_engine_create(const klab_model_cfg* cfg) {
   return e;
 }
 
+// Work the engine enqueued may still be running: on its own streams, and -- launched graphs, eager kernels -- on whatever
+// stream the caller passed last.  Nothing the engine owns is released before the device has drained it.
+static void drain_engine(klab_engine* e) {
+  if (!e->side && !e->own) return;  // never bound: nothing was ever enqueued
+  if (e->own) hipStreamSynchronize(e->own);
+  if (e->side) hipStreamSynchronize(e->side);
+  hipDeviceSynchronize();  // the caller's stream(s); destroy / rebind are rare, a device-wide wait is the simple safe form
+}
+
 extern "C" void klab_engine_destroy(klab_engine* e) {
   if (!e) return;
+  drain_engine(e);
+  for (auto& g : e->gs) if (g.exec) { hipGraphExecDestroy(g.exec); g.exec = nullptr; }
   if (e->ev_fork) hipEventDestroy(e->ev_fork);
   if (e->ev_join) hipEventDestroy(e->ev_join);
-  if (e->side) hipStreamDestroy(e->side);
   if (e->ev_in) hipEventDestroy(e->ev_in);
   if (e->ev_out) hipEventDestroy(e->ev_out);
+  for (auto ev : e->evpool) if (ev) hipEventDestroy(ev);
+  for (auto ev : e->ev0) if (ev) hipEventDestroy(ev);
+  for (auto ev : e->ev1) if (ev) hipEventDestroy(ev);
+  if (e->side) hipStreamDestroy(e->side);  // streams last: every event recorded on them is gone
   if (e->own) hipStreamDestroy(e->own);
-  for (auto& g : e->gs) if (g.exec) hipGraphExecDestroy(g.exec);
-  for (auto ev : e->evpool) hipEventDestroy(ev);
-  for (auto ev : e->ev0) hipEventDestroy(ev);
-  for (auto ev : e->ev1) hipEventDestroy(ev);
   delete e;
 }
 
@@ -945,7 +963,12 @@ extern "C" int klab_engine_segment(const klab_engine* e, int seg, int* model, lo
 
 extern "C" size_t klab_engine_workspace_bytes(klab_engine* e, int B, int Ls, int Lt) {
   if (!e || B <= 0 || Ls <= 0 || Lt <= 0) return 0;
-  klab_engine tmp = *e;  // plan on a scratch copy: bound state of `e` is untouched
+  // plan on a scratch engine that carries only what the plan reads (configuration, table sizes, arena extents): the bound
+  // state of `e` -- and its live stream / event / graph handles -- is neither touched nor copied
+  klab_engine tmp;
+  tmp.cfg = e->cfg;
+  for (int m = 0; m < 3; ++m) tmp.P[m].resize(e->P[m].size());
+  tmp.warena_elems = e->warena_elems; tmp.farena_elems = e->farena_elems;
   return plan_workspace(&tmp, nullptr, B, Ls, Lt);
 }
 
@@ -955,6 +978,9 @@ extern "C" int klab_engine_bind(klab_engine* e, int B, int Ls, int Lt, void* wor
                                 const void* const* swin_index, void* stream) {
   if (!e || !workspace || !swin_params || !lang_params || !main_params || !main_grads) return KLAB_ERR_BADARG;
   if (e->cfg.train_swin && !swin_grads) return KLAB_ERR_BADARG;
+  // a rebind (new batch shape / device): kernels and captured graphs of the previous binding may still be in flight and
+  // address the old workspace, which the caller releases after this call
+  if (e->bound) { e->bound = false; drain_engine(e); }
   const size_t need = plan_workspace(e, workspace, B, Ls, Lt);
   if (need > ws_bytes) return KLAB_ERR_BADARG;
   const void* const* src[3] = {swin_params, lang_params, main_params};
@@ -990,11 +1016,20 @@ extern "C" int klab_engine_bind(klab_engine* e, int B, int Ls, int Lt, void* wor
         const ParamInfo& p = e->P[m][i];
         if (p.warena_off < 0) continue;
         if (p.numel % 4) return KLAB_ERR_UNSUPPORTED;
+        if (m == 0 && (int)i == e->si.pew && e->pe_kp != e->pe_k0) {  // row by row into the padded pitch
+          if (e->pe_k0 % 4) return KLAB_ERR_UNSUPPORTED;
+          for (int r = 0; r < e->cfg.swin.embed_dim; ++r) {
+            d.push_back((long)(e->W[m][i] + (long)r * e->pe_k0)); d.push_back(p.warena_off + (long)r * e->pe_kp); d.push_back(pre);
+            pre += e->pe_k0 / 4; ++n;
+          }
+          continue;
+        }
         d.push_back((long)e->W[m][i]); d.push_back(p.warena_off); d.push_back(pre);
         pre += p.numel / 4; ++n;
       }
     }
-    void* dst = grp == 0 ? e->cast_desc : (void*)((char*)e->cast_desc + sizeof(long) * 3 * e->P[2].size() + sizeof(long) * 3 * e->P[0].size());
+    const size_t grp_cap = e->P[0].size() + e->P[1].size() + e->P[2].size() + e->cfg.swin.embed_dim + 1;
+    void* dst = grp == 0 ? e->cast_desc : (void*)((char*)e->cast_desc + sizeof(long) * 3 * grp_cap);
     if (grp == 1) { e->cast_desc_frozen = dst; e->n_cast_frozen = n; e->cast_total4_frozen = pre; }
     if (n == 0) { if (grp == 0) { e->n_cast = 0; e->cast_total4 = 0; } continue; }
     hipError_t er0 = hipMemcpyAsync(dst, d.data(), d.size() * sizeof(long), hipMemcpyHostToDevice, hs);
@@ -1005,6 +1040,9 @@ extern "C" int klab_engine_bind(klab_engine* e, int B, int Ls, int Lt, void* wor
     e->n_cast = n; e->cast_total4 = pre;
   }
   e->frozen_valid = false;
+  if (e->pe_kp != e->pe_k0)  // the padding columns of the patch-embedding weight rows: written here, never again
+    RC((int)hipMemsetAsync((char*)e->warena + (size_t)e->P[0][e->si.pew].warena_off * e->es, 0,
+                           (size_t)e->cfg.swin.embed_dim * e->pe_kp * e->es, hs));
   {
     std::vector<long> d;
     long pre = 0; int n = 0;
@@ -1066,7 +1104,7 @@ extern "C" int klab_engine_bind(klab_engine* e, int B, int Ls, int Lt, void* wor
     if (er != hipSuccess) return (int)er;
   }
   RC((int)hipMemsetAsync(e->seed_dev, 0, 512, hs));
-  for (auto& g : e->gs) {
+  for (auto& g : e->gs) {  // rebinding drops the captured graphs (drained above)
     if (g.exec) hipGraphExecDestroy(g.exec);
     g = klab_engine::GraphSlot();
   }
@@ -1088,6 +1126,7 @@ extern "C" int klab_engine_bind(klab_engine* e, int B, int Ls, int Lt, void* wor
 namespace {
 
 __global__ void seed_set_kernel(uint32_t* st, uint32_t base) { st[1] = base; st[2] = 0; }
+__global__ void seed_restore_kernel(uint32_t* st, uint32_t base, uint32_t counter) { st[1] = base; st[2] = counter; }
 __global__ void seed_step_kernel(uint32_t* st) {
   const uint32_t n = st[2] + 1;
   st[2] = n;
@@ -1165,10 +1204,6 @@ int forward_part_a(klab_engine* e, hipStream_t stream, float p, bool refresh_fro
     RC((int)hipEventRecord(e->ev_join, e->side));
   }
   RC((int)hipStreamWaitEvent(c.s, e->ev_join, 0));
-  if (e->weights_ev && e->weights_ev_defer) {  // the optimizer step of the previous iteration ran beside the frozen towers
-    RC((int)hipStreamWaitEvent(c.s, e->weights_ev, 0));
-    e->weights_ev = nullptr;
-  }
   // 4. T5 encoder (HF/t5:1009-1016)
   RC(t5_stack_forward(c, cfg.main, e->P[2], e->W[2], e->mi.enc, e->mi.enc_final, e->enc, false, STACK_ENC, p, B, nullptr, 0, 0, nullptr, 0, 0, 0,
                       p));
@@ -1203,9 +1238,22 @@ extern "C" int klab_engine_adam_step_segment(klab_engine* e, int segment, float*
                               bias_corr1, bias_corr2, stream);
 }
 
-extern "C" int klab_engine_set_weight_event(klab_engine* e, void* hip_event) {
-  if (!e) return KLAB_ERR_BADARG;
-  e->weights_ev = (hipEvent_t)hip_event;
+// Device-side dropout RNG of the binding: st[1] = base seed, st[2] = number of forwards since it was (re)seeded; every forward
+// derives its masks from hash(base, counter).  A resumed run restores both so that it continues the mask stream instead of
+// replaying it from step 1 (checkpoint.py).
+extern "C" int klab_engine_get_rng(klab_engine* e, uint32_t* base, uint32_t* counter, void* stream) {
+  if (!e || !e->bound || !base || !counter) return KLAB_ERR_BADARG;
+  uint32_t st[3] = {0, 0, 0};
+  RC((int)hipMemcpyAsync(st, e->seed_dev, sizeof(st), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  RC((int)hipStreamSynchronize((hipStream_t)stream));
+  *base = e->seed_set ? st[1] : e->seed_base;
+  *counter = e->seed_set ? st[2] : 0;
+  return KLAB_OK;
+}
+extern "C" int klab_engine_set_rng(klab_engine* e, uint32_t base, uint32_t counter, void* stream) {
+  if (!e || !e->bound) return KLAB_ERR_BADARG;
+  hipLaunchKernelGGL(seed_restore_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, e->seed_dev, base, counter);
+  e->seed_base = base; e->seed_set = true;  // the next forward with this base keeps the counter
   return KLAB_OK;
 }
 
@@ -1250,12 +1298,6 @@ extern "C" int klab_engine_forward(klab_engine* e, const float* pixels, const lo
   // bit 3: same images, prompt and weights as the previous forward of this binding, evaluation mode: only the decoder and the
   // LM head run (greedy decoding, ref/models/model.py:28).  Ignored under graph replay and whenever gradients are wanted.
   const bool ecur = (training & 8) && !(training & 1) && !want_grad && !e->use_graph && e->frozen_valid && !refresh_frozen;
-  if (e->weights_ev) {
-    // trainable weights are still being written on another stream: the frozen towers may start, the first kernel that reads a
-    // trainable tensor waits (forward_part_a); every other situation (cast of the masters, graph replay, decoder-only re-entry) waits now
-    e->weights_ev_defer = tcur && !ecur && !e->use_graph;
-    if (!e->weights_ev_defer) { RC((int)hipStreamWaitEvent(c.s, e->weights_ev, 0)); e->weights_ev = nullptr; }
-  }
   if (refresh_frozen) {  // not worth a graph slot: happens once per weight version
     RC(forward_part_a(e, c.s, p, true, tcur));
     e->frozen_valid = true;
@@ -1309,6 +1351,7 @@ extern "C" int klab_engine_probe_read(klab_engine* e, int* launches, float* tota
 }
 extern "C" const float* klab_engine_loss_ptr(const klab_engine* e) { return e ? e->loss : nullptr; }
 extern "C" const int* klab_engine_err_ptr(const klab_engine* e) { return e ? e->err_dev : nullptr; }
+extern "C" const uint32_t* klab_engine_rng_ptr(const klab_engine* e) { return e ? e->seed_dev : nullptr; }
 
 extern "C" const void* klab_engine_buffer(const klab_engine* e, const char* name, long* rows, long* cols, int* dtype) {
   if (!e || !e->bound || !name) return nullptr;
@@ -1487,7 +1530,7 @@ int swin_backward(const Ctx& c, const float* dh0, float p_in) {
   RC(klab_layernorm_bwd(dh, e->pe_out, c.dt, W[e->si.penw], e->pe_mean, e->pe_rstd, e->sdy, G(e->si.penw), G(e->si.penb), (int)M0, C0, 0, 0, 0,
                         0.f, nullptr, 0, c.ws()));
   RC(klab_colsum(e->sdy, C0, c.dt, (int)M0, C0, G(e->si.peb), c.ws()));
-  RC(linear_wgrad(c, e->sdy, C0, e->cols, (c.dt == KLAB_BF16 && s.patch == 4) ? ((K0 + 31) & ~31) : K0, (int)M0, C0, K0, G(e->si.pew)));
+  RC(linear_wgrad(c, e->sdy, C0, e->cols, e->pe_kp, (int)M0, C0, K0, G(e->si.pew)));
   return 0;
 }
 

@@ -114,15 +114,17 @@ ENGINE_SIGS = {
     "klab_engine_forward": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_void_p], C.c_int),
     "klab_engine_backward": ([C.c_void_p, C.c_int, C.c_void_p, C.c_void_p], C.c_int),
     "klab_engine_set_graph": ([C.c_void_p, C.c_int], C.c_int),
+    "klab_engine_get_rng": ([C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p], C.c_int),
+    "klab_engine_set_rng": ([C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p], C.c_int),
     "klab_engine_adam_step": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                C.c_float, C.c_void_p], C.c_int),
     "klab_engine_adam_step_segment": ([C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                        C.c_float, C.c_float, C.c_void_p], C.c_int),
-    "klab_engine_set_weight_event": ([C.c_void_p, C.c_void_p], C.c_int),
     "klab_engine_probe_enable": ([C.c_void_p, C.c_int], C.c_int),
     "klab_engine_probe_read": ([C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_double)], C.c_int),
     "klab_engine_loss_ptr": ([C.c_void_p], C.c_void_p),
     "klab_engine_err_ptr": ([C.c_void_p], C.c_void_p),
+    "klab_engine_rng_ptr": ([C.c_void_p], C.c_void_p),
     "klab_engine_buffer": ([C.c_void_p, C.c_char_p, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_int)], C.c_void_p),
     "klab_gelu_fwd": ([C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_void_p], C.c_int),
     "klab_swin_cpb_bias_bwd": ([C.c_void_p] * 11 + [C.c_int] * 4 + [C.c_void_p], C.c_int),
@@ -317,6 +319,8 @@ class Engine:
         ep = self._lib.klab_engine_err_ptr(self._h)
         eo = ep - ws.data_ptr()
         self.err_view = ws[eo:eo + 4].view(torch.int32)
+        ro = self._lib.klab_engine_rng_ptr(self._h) - ws.data_ptr()
+        self.rng_view = ws[ro:ro + 12].view(torch.int32)  # {step seed, base seed, forwards since seeding}
 
     @property
     def n_img(self):
@@ -342,10 +346,14 @@ class Engine:
         L.check(self._lib.klab_engine_adam_step(self._h, m.data_ptr(), v.data_ptr(), lr, beta1, beta2, eps, weight_decay, bias_corr1,
                                                 bias_corr2, L.stream_ptr()), "klab_engine_adam_step")
 
-    def set_weight_event(self, event):
-        """`event` (torch.cuda.Event recorded behind an optimizer step on another stream, or None): the next forward waits for it
-        only in front of its first use of a trainable tensor.  The caller keeps the event alive until that forward is enqueued."""
-        L.check(self._lib.klab_engine_set_weight_event(self._h, None if event is None else event.cuda_event), "klab_engine_set_weight_event")
+    def get_rng(self):
+        """(base seed, forwards since seeding) of the device-side dropout RNG; synchronises the current stream"""
+        b, n = C.c_uint32(), C.c_uint32()
+        L.check(self._lib.klab_engine_get_rng(self._h, C.byref(b), C.byref(n), L.stream_ptr()), "klab_engine_get_rng")
+        return int(b.value), int(n.value)
+
+    def set_rng(self, base, counter):
+        L.check(self._lib.klab_engine_set_rng(self._h, int(base) & 0xFFFFFFFF, int(counter) & 0xFFFFFFFF, L.stream_ptr()), "klab_engine_set_rng")
 
     def set_graph(self, on=True):
         """replay the launch sequences as hipGraphs (inputs are staged, so any input tensors may be passed)."""

@@ -210,10 +210,10 @@ class MyModel(nn.Module):
         self._direct_grads = False
         self._segment_hook = None
         self._pending_reduce = None  # klab DDP(overlap_optimizer=True): reducer whose last all-reduces are not joined yet
-        self._weights_event = None   # FusedAdam(overlap_next_forward=True): update possibly still running on its own stream
         self.use_graph = os.environ.get("KLAB_GRAPH", "0") == "1"  # hipGraph replay of the engine's launch sequences
         self._seed_base = torch.initial_seed() & 0xFFFFFFFF
         self._seed_ctr = 0
+        self._pending_rng = None  # (base, counter) restored by load_checkpoint, applied at the next bind
         self._frozen_fp = None
         self._train_fp = None  # version fingerprint of the trainable T5 right after a klab FusedAdam step (bf16 copies current)
         self._fwd_token = 0
@@ -277,6 +277,9 @@ class MyModel(nn.Module):
                 self._views = None
             eng.bind(B, Ls, Lt, tensors, self._flat["main"], self._flat["swin"], dev)
             eng.set_graph(self.use_graph)
+            if self._pending_rng is not None:  # load_checkpoint before the first forward: continue the saved dropout stream
+                eng.set_rng(*self._pending_rng)
+                self._pending_rng = None
             self._bound_key = key
             self._frozen_fp = None
             self._train_fp = None
@@ -373,13 +376,7 @@ class MyModel(nn.Module):
         start = torch.full((B, 1), cfg.decoder_start_token_id, dtype=torch.int64, device=src.device)
         return torch.cat([start, tgt], dim=1)
 
-    def _join_weights(self):
-        """the current stream waits for an optimizer update that runs on its own stream (FusedAdam overlap_next_forward)"""
-        if self._weights_event is not None:
-            torch.cuda.current_stream().wait_event(self._weights_event)
-
     def save(self, result_name="best.pth"):
-        self._join_weights()
         result_path = os.path.join(self.args.result_dir, result_name)
         checkpoints = {'transformer': self.transformer.state_dict()}
         if self.args.image_model_train:

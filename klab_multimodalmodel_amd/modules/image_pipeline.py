@@ -51,17 +51,39 @@ class GpuImageProcessor:
         self.rescale = (1.0 / 255.0) * float(rescale_factor)
         self.device = torch.device(device)
 
+    # `preprocessor_config.json` of the hub checkpoints the reference's CLI accepts (ref/modules/config.py:6-7), restated from
+    # the public model cards: ViTImageProcessor, 256x256, BICUBIC, ImageNet mean / std.  Used when the NAME is given and no
+    # local directory exists (no hub access here); anything else must be a local directory or explicit keyword arguments.
+    KNOWN = {name: dict(size=256, resample=BICUBIC, rescale_factor=1 / 255, image_mean=(0.485, 0.456, 0.406),
+                        image_std=(0.229, 0.224, 0.225))
+             for name in ("microsoft/swinv2-tiny-patch4-window8-256", "microsoft/swinv2-small-patch4-window8-256",
+                          "microsoft/swinv2-base-patch4-window8-256", "microsoft/swinv2-base-patch4-window16-256")}
+
     @classmethod
     def from_pretrained(cls, path=None, **kw):
-        """reads `preprocessor_config.json` from a local directory when given one (no hub access here)"""
+        """`AutoImageProcessor.from_pretrained(args.image_model_name)` (ref/train.py:39): a local directory with
+        `preprocessor_config.json`, or one of the KNOWN hub names.  Anything else raises OSError like the reference does
+        offline -- it never falls back to bare ViTImageProcessor defaults (a silent 224 / bilinear / 0.5-mean pipeline for a
+        256 / bicubic / ImageNet checkpoint).  Explicit keyword arguments alone (path=None) build a processor directly."""
         import json
         import os
-        cfg = {}
-        if path and os.path.isdir(path) and os.path.exists(os.path.join(path, "preprocessor_config.json")):
-            with open(os.path.join(path, "preprocessor_config.json")) as f:
-                cfg = json.load(f)
         keys = ("size", "resample", "rescale_factor", "image_mean", "image_std")
-        return cls(**{**{k: cfg[k] for k in keys if k in cfg}, **kw})
+        if path is None:
+            if not kw:
+                raise OSError("GpuImageProcessor.from_pretrained needs a local directory, a known checkpoint name or explicit settings")
+            return cls(**kw)
+        cfg_file = os.path.join(path, "preprocessor_config.json") if os.path.isdir(path) else None
+        if cfg_file and os.path.exists(cfg_file):
+            with open(cfg_file) as f:
+                cfg = json.load(f)
+            for flag in ("do_resize", "do_rescale", "do_normalize"):
+                if cfg.get(flag, True) is False:
+                    raise NotImplementedError(f"preprocessor_config.json sets {flag}=false: outside the reference's pipeline")
+            return cls(**{**{k: cfg[k] for k in keys if k in cfg}, **kw})
+        if path in cls.KNOWN:
+            return cls(**{**cls.KNOWN[path], **kw})
+        raise OSError(f"Can't load image processor for '{path}': not a local directory containing preprocessor_config.json and not "
+                      f"one of {sorted(cls.KNOWN)} (this build has no hub access).")
 
     def _out(self, n):
         return torch.empty(n, 3, self.size, self.size, dtype=torch.float32, device=self.device)

@@ -16,13 +16,7 @@ from torch.optim import Optimizer
 
 
 class FusedAdam(Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, *, maximize=False,
-                 overlap_next_forward=False):
-        """overlap_next_forward=True: the update kernel runs on its own stream and the NEXT `model(...)` call starts its frozen
-        towers (Swin, language encoder) beside it, waiting only in front of the first kernel that reads a trainable weight
-        (`klab_engine_set_weight_event`).  For loops that go straight from `step()` / `zero_grad()` to the next forward (the
-        reference's, ref/train.py:58-71); `state_dict()`, `MyModel.save()`, `generate()` and checkpointing join by themselves,
-        any other direct read of a parameter between `step()` and the next forward must call `optimizer.join()` first."""
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, *, maximize=False):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
             raise ValueError("invalid Adam hyper-parameter")
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, maximize=maximize)
@@ -32,19 +26,6 @@ class FusedAdam(Optimizer):
         self._owner = None
         self._fallback = None
         self._fb_reason = None
-        self.overlap_next_forward = bool(overlap_next_forward)
-        self._opt_stream = None
-        self._ev = None
-
-    def join(self):
-        """the current stream waits for an update still running on the optimizer stream (overlap_next_forward)"""
-        if self._ev is not None:
-            torch.cuda.current_stream().wait_event(self._ev)
-
-    def zero_grad(self, set_to_none=True):
-        if not set_to_none:
-            self.join()  # the zeroing kernels would race with the update's reads of the gradients
-        return super().zero_grad(set_to_none=set_to_none)
 
     # ---- which model owns these parameters -------------------------------------------------------------------------
     def _find_owner(self):
@@ -120,25 +101,12 @@ class FusedAdam(Optimizer):
             else:
                 model._engine.adam_step(self._m, self._v, *hyper)
 
-        if self.overlap_next_forward and flat.is_cuda:
-            cur = torch.cuda.current_stream(flat.device)
-            if self._opt_stream is None:
-                self._opt_stream = torch.cuda.Stream(device=flat.device)
-                self._ev = torch.cuda.Event()
-            self._opt_stream.wait_stream(cur)  # gradients (and the previous forward's reads of the weights) are complete
-            with torch.cuda.stream(self._opt_stream):
-                launch()
-                self._ev.record(self._opt_stream)
-            model._engine.set_weight_event(self._ev)  # the next forward waits in front of its first trainable-weight read
-            model._weights_event = self._ev
-        else:
-            launch()
+        launch()
         model._note_optimizer_step()
         self._owner = weakref.ref(model)
         return loss
 
     def _step_fallback(self):
-        self.join()
         if self._fallback is None:
             self._fallback = _TorchAdam(self.param_groups, fused=all(p.is_cuda for g in self.param_groups for p in g["params"]) or None)
             self._fallback.param_groups = self.param_groups  # share the group dicts (LR schedulers act on ours)
@@ -157,7 +125,6 @@ class FusedAdam(Optimizer):
 
     def state_dict(self):
         """torch.optim.Adam-compatible: per-parameter `step`, `exp_avg`, `exp_avg_sq` (copies)."""
-        self.join()
         if self._fallback is not None:
             return self._fallback.state_dict()
         model = self._owner() if self._owner is not None else None
@@ -173,7 +140,6 @@ class FusedAdam(Optimizer):
     def load_state_dict(self, state_dict):
         """torch.optim.Adam-compatible.  The model must have been bound to a batch shape (one forward) so that the flat state
         layout is known; otherwise the loaded state is kept per parameter and the torch fallback continues from it."""
-        self.join()
         super().load_state_dict(state_dict)
         model = self._find_owner()
         steps = 0

@@ -246,3 +246,24 @@ def test_async_checkpointer_roundtrip_and_reference_schema(built, tmp_path):
     assert s.keys() == s3.keys() and all(torch.equal(s[k]["exp_avg"], s3[k]["exp_avg"]) for k in s)
     for (k, x), (_, y) in zip(m.image_model.state_dict().items(), m3.image_model.state_dict().items()):
         assert torch.equal(x, y), k
+
+
+def test_image_processor_from_pretrained_never_silently_defaults(tmp_path):
+    """ref/train.py:39 `AutoImageProcessor.from_pretrained(args.image_model_name)`: a hub name without a local config must not
+    yield bare ViTImageProcessor defaults (224 / bilinear / mean 0.5) for a 256 / bicubic / ImageNet checkpoint."""
+    from klab_multimodalmodel_amd.modules.image_pipeline import BICUBIC, GpuImageProcessor
+    with pytest.raises(OSError):
+        GpuImageProcessor.from_pretrained("someone/unknown-checkpoint", device="cpu")
+    with pytest.raises(OSError):
+        GpuImageProcessor.from_pretrained(str(tmp_path), device="cpu")  # a directory without preprocessor_config.json
+    with pytest.raises(OSError):
+        GpuImageProcessor.from_pretrained()
+    p = GpuImageProcessor.from_pretrained("microsoft/swinv2-base-patch4-window8-256", device="cpu")  # the reference's default name
+    assert p.size == 256 and p.resample == BICUBIC and abs(p.mean[0] - 0.485) < 1e-9 and abs(p.std[2] - 0.225) < 1e-9
+    with open(os.path.join(str(tmp_path), "preprocessor_config.json"), "w") as f:
+        json.dump({"size": {"height": 192, "width": 192}, "resample": 3, "image_mean": [0.1, 0.2, 0.3], "image_std": [0.5, 0.5, 0.5],
+                   "rescale_factor": 0.00392156862745098, "image_processor_type": "ViTImageProcessor"}, f)
+    q = GpuImageProcessor.from_pretrained(str(tmp_path), device="cpu")
+    assert q.size == 192 and q.resample == 3 and q.mean == (0.1, 0.2, 0.3)
+    r = GpuImageProcessor.from_pretrained(size=224, device="cpu")  # explicit settings only
+    assert r.size == 224

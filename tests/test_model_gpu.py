@@ -175,7 +175,22 @@ def test_full_size_architecture_matches_oracle(dtype, loss_tol, cos_min):
     assert c > cos_min
 
 
-def _train_steps(wrap, accumulate=1, steps=3, fused_adam=False, overlap=False, adam_overlap=False):
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _drop_engines():
+    """every model / engine of the caller is gone and the device is idle (klab DDP-wrapped models sit in a reference cycle
+    with their wrapper, so only the cyclic collector frees them)"""
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+
+
+def _train_steps(wrap, accumulate=1, steps=3, fused_adam=False, overlap=False):
     """the reference's loop body (ref/train.py:58-71) on a tiny config; returns losses and final weights."""
     import torch.distributed as dist
     m, g = build("tiny_b", torch.float32, True)
@@ -191,7 +206,7 @@ def _train_steps(wrap, accumulate=1, steps=3, fused_adam=False, overlap=False, a
         model = core = m
     if fused_adam:
         from klab_multimodalmodel_amd.optim import FusedAdam
-        opt = FusedAdam(core.transformer.parameters(), lr=1e-3, overlap_next_forward=adam_overlap)
+        opt = FusedAdam(core.transformer.parameters(), lr=1e-3)
     else:
         opt = torch.optim.Adam(core.transformer.parameters(), lr=1e-3)
     losses = []
@@ -204,11 +219,13 @@ def _train_steps(wrap, accumulate=1, steps=3, fused_adam=False, overlap=False, a
                 model.join()  # a consumer other than FusedAdam has to join the pending all-reduces itself
             opt.step()
             opt.zero_grad()
-    if adam_overlap:
-        opt.join()  # parameters are read directly below
     w = {k: v.detach().clone() for k, v in core.transformer.state_dict().items()}
     sg = core.image_model.get_parameter("layernorm.weight").grad
-    return losses, w, None if sg is None else sg.detach().clone()
+    sg = None if sg is None else sg.detach().clone()
+    torch.cuda.synchronize()
+    del model, core, m, opt, loss  # the engine (its streams, events) goes before the caller tears the process group down
+    _drop_engines()
+    return losses, w, sg
 
 
 def test_reference_training_loop_under_stock_ddp_and_klab_ddp():
@@ -216,9 +233,7 @@ def test_reference_training_loop_under_stock_ddp_and_klab_ddp():
     Stock torch DDP (autograd-hook path), klab DDP (direct flat-gradient path) and no wrapper must agree."""
     import os
     import torch.distributed as dist
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
-    dist.init_process_group("nccl", rank=0, world_size=1)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
     try:
         for acc in (1, 2):
             l0, w0, s0 = _train_steps(None, acc)
@@ -230,17 +245,12 @@ def test_reference_training_loop_under_stock_ddp_and_klab_ddp():
                 l4, w4, _s4 = _train_steps("klab", acc, fused_adam=True)
                 # overlap_optimizer: backward leaves the last all-reduces unjoined, FusedAdam updates segment by segment
                 l5, w5, _s5 = _train_steps("klab", acc, fused_adam=True, overlap=True)
-                # ... and with the update on its own stream beside the next forward's frozen towers (what bench.py runs at N > 1)
-                l7, w7, _s7 = _train_steps("klab", acc, fused_adam=True, overlap=True, adam_overlap=True)
                 l6, w6, _s6 = _train_steps("klab", acc, fused_adam=False, overlap=True)  # torch Adam behind an explicit ddp.join()
             finally:
                 del os.environ["KLAB_DDP_FORCE_COLLECTIVE"]
             assert max(abs(x - y) for x, y in zip(l0, l4)) < 2e-4, (acc, l0, l4)
             assert max(abs(x - y) for x, y in zip(l0, l5)) < 2e-4, (acc, l0, l5)
             assert max(abs(x - y) for x, y in zip(l0, l6)) < 2e-4, (acc, l0, l6)
-            assert max(abs(x - y) for x, y in zip(l0, l7)) < 2e-4, (acc, l0, l7)
-            for k in w0:
-                assert rel_l2(w7[k].cpu(), w0[k].cpu()) < 2e-3, k
             for k in w0:
                 assert rel_l2(w4[k].cpu(), w0[k].cpu()) < 2e-3, k
                 assert rel_l2(w5[k].cpu(), w0[k].cpu()) < 2e-3, k
@@ -257,6 +267,7 @@ def test_reference_training_loop_under_stock_ddp_and_klab_ddp():
             assert s0 is not None and s1 is not None and s2 is not None
             assert rel_l2(s1.cpu(), s0.cpu()) < 1e-3 and rel_l2(s2.cpu(), s0.cpu()) < 1e-3
     finally:
+        _drop_engines()  # no engine, comm stream or in-flight collective is left when the communicator goes
         dist.destroy_process_group()
 
 
@@ -294,6 +305,7 @@ def test_hipgraph_replay_matches_eager():
             out.append((loss.item(), gq, gs))
             m.zero_grad(set_to_none=True)
         res[graph] = out
+        del m, loss  # (klab_engine_destroy drains in-flight replays itself: test_engine_teardown_with_work_in_flight)
     for (l0, q0, s0), (l1, q1, s1) in zip(res[False], res[True]):
         assert abs(l0 - l1) <= 1e-6 * abs(l0)
         assert rel_l2(q1.cpu(), q0.cpu()) < 1e-5 and rel_l2(s1.cpu(), s0.cpu()) < 1e-4
@@ -309,6 +321,36 @@ def test_hipgraph_replay_matches_eager():
         ls.append(loss.item())
         m.zero_grad(set_to_none=True)
     assert len(set(ls)) == 5
+
+
+def test_engine_teardown_with_work_in_flight():
+    """Regression for the round-1 GPU-suite crash: an engine dropped or re-bound while its last backward --
+    eager kernels on the side stream, or replayed hipGraphs on the caller's stream -- is still executing.  klab_engine_destroy /
+    klab_engine_bind now drain the device before they release graph executables, events, streams and (the caller) the
+    workspace; the next engine's results must be unaffected."""
+    ref = None
+    for graph in (False, True, True):
+        m, g = build("tiny_b", torch.float32, True)
+        m.use_graph = graph
+        m.transformer.eval()
+        for _ in range(3):  # eager, captured, replayed
+            loss = run(m, g)
+            loss.backward()
+            m.zero_grad(set_to_none=True)
+        loss = run(m, g)
+        loss.backward()  # left in flight: no synchronisation before the model goes
+        lv = loss  # (device scalar: reading it below is the first sync)
+        gq = m.transformer.get_parameter("decoder.block.0.layer.1.EncDecAttention.q.weight").grad
+        # re-bind to another batch shape with the previous backward still running, then drop everything
+        inp = g["inputs"]
+        m({"pixel_values": inp["pixel_values"][:1].cuda()}, {"input_ids": inp["src_ids"][:1].cuda()}, {"input_ids": inp["tgt_ids"][:1].cuda()})
+        val = (float(lv), gq.detach().clone())
+        del m, loss, lv, gq
+        if ref is None:
+            ref = val
+        else:
+            assert abs(val[0] - ref[0]) <= 1e-6 * abs(ref[0])
+    torch.cuda.synchronize()
 
 
 def test_frozen_tower_caches_follow_weight_updates():
@@ -334,8 +376,8 @@ def test_frozen_tower_caches_follow_weight_updates():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("wd,overlap", [(0.0, False), (0.01, False), (0.01, True)])
-def test_fused_adam_matches_torch_adam(dtype, wd, overlap):
+@pytest.mark.parametrize("wd", [0.0, 0.01])
+def test_fused_adam_matches_torch_adam(dtype, wd):
     """optim.FusedAdam (one kernel over the flat buffers, bf16 copies refreshed, forward's cast skipped) follows
     torch.optim.Adam (ref/train.py:28) step for step: same parameters after 4 steps in eval mode (no dropout noise)."""
     from klab_multimodalmodel_amd.optim import FusedAdam
@@ -345,8 +387,7 @@ def test_fused_adam_matches_torch_adam(dtype, wd, overlap):
         m._direct_grads = True
         m.transformer.eval()
         ps = list(m.transformer.parameters())
-        # overlap: the update runs on its own stream beside the next forward's frozen towers (overlap_next_forward)
-        opts.append(FusedAdam(ps, lr=3e-3, weight_decay=wd, overlap_next_forward=overlap) if fused else torch.optim.Adam(ps, lr=3e-3, weight_decay=wd))
+        opts.append(FusedAdam(ps, lr=3e-3, weight_decay=wd) if fused else torch.optim.Adam(ps, lr=3e-3, weight_decay=wd))
         ms.append(m)
     losses = [[], []]
     for step in range(4):
@@ -357,7 +398,6 @@ def test_fused_adam_matches_torch_adam(dtype, wd, overlap):
             opts[k].zero_grad()
             losses[k].append(float(loss))
     assert opts[1]._fallback is None, opts[1]._fb_reason          # the one-kernel path really ran
-    opts[1].join()                                                 # (overlap: parameters are read directly below)
     assert ms[1]._trainable_current()                              # ... and the next forward would skip its cast
     tol = 2e-5 if dtype == torch.float32 else 2e-3                 # bf16: both sides see bf16-rounded gradients of slightly different weights
     for a, b in zip(losses[0], losses[1]):
@@ -416,6 +456,59 @@ def test_checkpoint_resume_with_fused_adam(tmp_path):
     assert o2._fallback is None, o2._fb_reason
     for a, b in zip(ref, first + rest):
         assert abs(a - b) <= 2e-5 * abs(a) + 1e-6, (ref, first + rest)
+
+
+@pytest.mark.gpu
+def test_resume_continues_the_dropout_stream(tmp_path):
+    """true resume with dropout ON: the engine's device-side RNG (base seed + forward counter) and the model's seed base are
+    part of the checkpoint, so 2 steps + save + load into a fresh model + 2 steps reproduce 4 uninterrupted train-mode steps
+    (without them the resumed run would replay the masks of steps 1-2)."""
+    from klab_multimodalmodel_amd.checkpoint import AsyncCheckpointer, load_checkpoint
+    from klab_multimodalmodel_amd.optim import FusedAdam
+
+    def make(seed_base):
+        m, g = build("tiny_a", torch.float32, False)
+        m._seed_base = seed_base
+        m._direct_grads = True
+        m.transformer.train()
+        return m, g, FusedAdam(m.transformer.parameters(), lr=2e-3)
+
+    def steps(m, g, opt, n):
+        out = []
+        for _ in range(n):
+            loss = run(m, g)
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+            out.append(float(loss))
+        return out
+
+    m0, g, o0 = make(1234)
+    ref = steps(m0, g, o0, 4)
+    assert len(set(ref)) == 4
+    m1, g, o1 = make(1234)
+    first = steps(m1, g, o1, 2)
+    assert m1._engine.get_rng() == (1234, 2)
+    ck = AsyncCheckpointer(str(tmp_path))
+    ck.save(m1, o1, None, step=2, name="d.pth")
+    ck.wait()
+    for early in (False, True):  # load after one binding forward / before any forward (state applied at bind)
+        m2, g, o2 = make(999)  # a different base: the checkpoint's must win
+        if not early:
+            run(m2, g)
+            assert load_checkpoint(os.path.join(str(tmp_path), "d.pth"), m2, o2) == 2
+            rest = steps(m2, g, o2, 2)
+            assert o2._fallback is None, o2._fb_reason
+            for a, b in zip(ref, first + rest):
+                assert abs(a - b) <= 2e-5 * abs(a) + 1e-6, (ref, first + rest)
+        else:
+            ckd = torch.load(os.path.join(str(tmp_path), "d.pth"), weights_only=False)
+            assert ckd["engine_rng"]["seed_base"] == 1234 and [int(x) for x in ckd["engine_rng"]["state"][1:]] == [1234, 2]
+            m2.transformer.load_state_dict(ckd["transformer"])
+            m2._seed_base = 1234
+            m2._pending_rng = (1234, 2)
+            l3 = float(run(m2, g))  # step 3's forward: same weights (before its update), same masks
+            assert abs(l3 - ref[2]) <= 2e-5 * abs(ref[2]) + 1e-6
 
 
 @pytest.mark.gpu
