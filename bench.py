@@ -1,17 +1,18 @@
 #!/usr/bin/env python3
 """Caption-training throughput of the native Swin-V2 -> T5 path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload caption|cfg3|spanmask|cfg5]
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 One step = what ref/train.py:58-67 does per iteration: loss = model(images, src, tgt); loss.backward();
 optimizer.step(); optimizer.zero_grad()  -- forward + backward of MyModel (libklab_mm.so engine), the
 gradient all-reduce over RCCL when N > 1 (klab DistributedDataParallel, overlapped per backward
-segment) and the reference's own torch.optim.Adam over transformer.parameters().
-Workload (BASELINE.json configs[1], resolved per SURVEY §8d to a reference-runnable width-matched
-pair): Swin-V2 C=64 (2,2,6,2)/(2,4,8,16) 224x224 w7 frozen + T5-small, bf16 operands with fp32
+segment) and the reference's Adam update over transformer.parameters().
+Default workload = BASELINE.json configs[1], resolved per SURVEY §8d to a reference-runnable width-matched
+pair: Swin-V2 C=64 (2,2,6,2)/(2,4,8,16) 224x224 w7 frozen + T5-small, bf16 operands with fp32
 accumulation, batch 64 per GPU, Ls=9, Lt=64, T5 dropout 0.1 ON, synthetic inputs already resident
-in HBM, random-init weights (no network).  Prints ONE JSON line on rank 0.
+in HBM, random-init weights (no network).  The other workloads are the per-GPU slices of configs[2..4]
+(parity-test cases and secondary data points, not the headline line).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -27,11 +28,32 @@ if "--graph" not in sys.argv:  # hipGraph replay is the exception: 16.6 ms/step 
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # see klab_multimodalmodel_amd/__init__.py: streams must not share HW queues
 import torch  # noqa: E402
 
-GFLOP_PER_SAMPLE = {"cfg2": 27.26}  # fwd+bwd algorithmic work, SURVEY §8d / BASELINE.md §3
 PEAK_BF16_TFLOPS = 2500.0           # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_FP8_TFLOPS = 5000.0            # dense fp8 MFMA peak, same table
+
+# per-GPU workloads = BASELINE.json configs as SURVEY §8(d) resolves them (fwd+bwd algorithmic GFLOP/sample from that table)
+WORKLOADS = {
+    "caption": dict(name="BASELINE configs[1]: Swin-V2(C=64,(2,2,6,2),224,w7) frozen + T5-small", gflop=27.26, B=64, Ls=9, Lt=64,
+                    swin=dict(image_size=224, embed_dim=64, depths=(2, 2, 6, 2), num_heads=(2, 4, 8, 16), window_size=7),
+                    t5=dict(), train_swin=False, span=False),
+    "cfg3": dict(name="BASELINE configs[2] per-GPU slice: Swin-V2(C=96,(2,2,18,2),224,w7) UNFROZEN + T5-base", gflop=137.27, B=32, Ls=9,
+                 Lt=64, swin=dict(image_size=224, embed_dim=96, depths=(2, 2, 18, 2), num_heads=(3, 6, 12, 24), window_size=7),
+                 t5=dict(d_model=768, d_ff=3072, num_heads=12, num_layers=12, num_decoder_layers=12), train_swin=True, span=False),
+    "spanmask": dict(name="BASELINE configs[3] per-GPU slice: RedCaps span-mask pretraining (<extra_id_k> sentinels), "
+                          "Swin-V2(C=96,(2,2,18,2),224,w7) UNFROZEN + T5-base", gflop=118.90, B=32, Ls=32, Lt=16,
+                     swin=dict(image_size=224, embed_dim=96, depths=(2, 2, 18, 2), num_heads=(3, 6, 12, 24), window_size=7),
+                     t5=dict(d_model=768, d_ff=3072, num_heads=12, num_layers=12, num_decoder_layers=12), train_swin=True, span=True),
+    "cfg5": dict(name="BASELINE configs[4] per-GPU slice: Swin-V2(C=128,(2,2,18,2),384,w24,pretrained (12,12,12,6)) UNFROZEN + T5-large",
+                 gflop=817.26, B=32, Ls=9, Lt=64,
+                 swin=dict(image_size=384, embed_dim=128, depths=(2, 2, 18, 2), num_heads=(4, 8, 16, 32), window_size=24,
+                           pretrained_window_sizes=(12, 12, 12, 6)),
+                 t5=dict(d_model=1024, d_ff=4096, num_heads=16, num_layers=24, num_decoder_layers=24), train_swin=True, span=False),
+}
+GFLOP_PER_SAMPLE = {"cfg2": WORKLOADS["caption"]["gflop"]}
 
 
 def synth_batch(B, Ls, Lt, H, vocab, device, seed=1234):
+    """SURVEY §8(d) synthetic inputs: N(0,1) pixels, uniform ids in [2, 32000), </s> last."""
     g = torch.Generator().manual_seed(seed)
     pix = torch.randn(B, 3, H, H, generator=g)
     src = torch.randint(2, 32000, (B, Ls), generator=g)
@@ -41,11 +63,45 @@ def synth_batch(B, Ls, Lt, H, vocab, device, seed=1234):
     return pix.to(device), src.to(device), tgt.to(device)
 
 
-def cfg2_configs():
+def synth_spanmask_batch(B, Ls, Lt, H, vocab, device, seed=1234, n_mask=4):
+    """SURVEY §8(d), span-mask configuration: the token ids the reference's RedCaps path produces after tokenisation
+    (ref/modules/loader.py:56-72, ref/train.py:56-57) -- `<extra_id_k>` = id 32099 - k (HF/t5tok:99-110).
+    src: random words with sentinels k = 0..n_mask-1 planted in increasing order, </s>, pad tail;
+    tgt: <extra_id_0> w <extra_id_1> w ... <extra_id_n_mask> </s>, padded with 0 to Lt (pads ARE scored: SURVEY §0.4);
+    25 % of the rows are shorter (more padding on both sides)."""
+    g = torch.Generator().manual_seed(seed)
+    pix = torch.randn(B, 3, H, H, generator=g)
+    src = torch.zeros(B, Ls, dtype=torch.int64)
+    tgt = torch.zeros(B, Lt, dtype=torch.int64)
+    for b in range(B):
+        short = (b % 4) == 3
+        ls = Ls - (Ls // 4 if short else 0)
+        words = torch.randint(2, 32000, (ls - 1,), generator=g)
+        pos = torch.sort(torch.randperm(ls - 1, generator=g)[:n_mask]).values
+        for k, p in enumerate(pos.tolist()):
+            words[p] = 32099 - k
+        src[b, :ls - 1] = words
+        src[b, ls - 1] = 1
+        row = []
+        for k in range(n_mask):
+            row.append(32099 - k)
+            nw = 1 if short else int(torch.randint(1, 3, (1,), generator=g))  # a masked word is 1-2 sentencepiece tokens
+            row.extend(torch.randint(2, 32000, (nw,), generator=g).tolist())
+        row.append(32099 - n_mask)
+        row.append(1)
+        row = row[:Lt]
+        tgt[b, :len(row)] = torch.tensor(row)
+    return pix.to(device), src.to(device), tgt.to(device)
+
+
+def workload_configs(name):
     from klab_multimodalmodel_amd.engine import SwinConfig, T5Config
-    sw = SwinConfig(image_size=224, embed_dim=64, depths=(2, 2, 6, 2), num_heads=(2, 4, 8, 16), window_size=7)
-    t5 = T5Config()  # t5-small
-    return sw, t5
+    w = WORKLOADS[name]
+    return SwinConfig(**w["swin"]), T5Config(**w["t5"])
+
+
+def cfg2_configs():
+    return workload_configs("caption")
 
 
 def usable_cores():
@@ -97,18 +153,31 @@ def cpu_baseline(budget_s=20.0):
             "sample": f"oracle fwd+bwd+Adam, configs[0] (B=2, fp32, Ls=9, Lt=64, 224px), median of {len(times)} steps after 2 warm-up"}
 
 
+def _traffic(key):
+    """HBM bytes per launch from the PMC passes kept under profiles/ (collected per MI355X_MICROARCH.md's rocprofv3 recipe)"""
+    tp = os.path.join(ROOT, "profiles", "kernel_traffic.json")
+    try:
+        return json.load(open(tp)).get(key, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE configs[1]: 64)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="caption",
+                    help="caption = BASELINE configs[1] (the headline metric); cfg3 / spanmask / cfg5 = per-GPU slices of configs[2..4]")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's, configs[1]: 64)")
+    ap.add_argument("--dtype", choices=["bf16", "fp8"], default="bf16", help="fp8: per-tensor-scaled fp8 MFMA GEMMs (configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--optimizer", choices=["klab", "torch"], default="klab",
                     help="klab: klab_multimodalmodel_amd.optim.FusedAdam (same update rule as torch.optim.Adam, one kernel); torch: torch.optim.Adam(fused=True)")
     ap.add_argument("--graph", action="store_true", help="replay the engine's launch sequences as hipGraphs (measured: no gain "
                     "while the step is GPU-bound; kept for when it becomes launch-bound)")
     a = ap.parse_args()
+    wl = WORKLOADS[a.workload]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -124,28 +193,32 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from klab_multimodalmodel_amd.models.model import MyModel
-    sw, t5 = cfg2_configs()
-    args = types.SimpleNamespace(result_dir="/tmp", language_model_name="t5-small", image_model_name="swinv2-C64-224-w7",
-                                 image_model_train=False, transformer_model_name="t5-small")
+    sw, t5 = workload_configs(a.workload)
+    args = types.SimpleNamespace(result_dir="/tmp", language_model_name="-", image_model_name="-",
+                                 image_model_train=wl["train_swin"], transformer_model_name="-")
     torch.manual_seed(0)
-    model = MyModel(args, _configs=(sw, t5, t5), _seed=0, dtype="bf16").to(dev)
+    model = MyModel(args, _configs=(sw, t5, t5), _seed=0, dtype=a.dtype).to(dev)
+    ddp = None
     if dist_on and os.environ.get("KLAB_BENCH_FORCE_DIST") != "2":  # "2": process group without the wrapper (diagnostic)
         from klab_multimodalmodel_amd.ddp import DistributedDataParallel as DDP
-        model = DDP(model, device_ids=[local_rank], overlap_optimizer=(a.optimizer == "klab" and os.environ.get("KLAB_BENCH_OVERLAP_OPT", "1") == "1"))
+        model = ddp = DDP(model, device_ids=[local_rank],
+                          overlap_optimizer=(a.optimizer == "klab" and os.environ.get("KLAB_BENCH_OVERLAP_OPT", "1") == "1"))
         core = model.module
     else:
         core = model
         core._direct_grads = True  # grads land in the flat buffer (no autograd copies); same math
     core.use_graph = bool(a.graph)  # forward / backward launch sequences replayed as hipGraphs (same kernels, same math)
+    lr = 1e-3 if a.workload == "caption" else 1e-4
     if a.optimizer == "klab":  # torch.optim.Adam's update rule in one kernel over the flat buffers (+ bf16 weight copies)
         from klab_multimodalmodel_amd.optim import FusedAdam
-        optimizer = FusedAdam(core.transformer.parameters(), lr=1e-3)
+        optimizer = FusedAdam(core.transformer.parameters(), lr=lr)
     else:                      # ref/train.py:28 verbatim (torch's own fused multi-tensor kernel)
-        optimizer = torch.optim.Adam(core.transformer.parameters(), lr=1e-3, fused=True)
+        optimizer = torch.optim.Adam(core.transformer.parameters(), lr=lr, fused=True)
     core.transformer.train()                                               # ref/train.py:52
 
-    B, Ls, Lt = a.batch, 9, 64
-    pix, src, tgt = synth_batch(B, Ls, Lt, 224, 32128, dev, seed=1234 + rank)
+    B, Ls, Lt = (a.batch or wl["B"]), wl["Ls"], wl["Lt"]
+    synth = synth_spanmask_batch if wl["span"] else synth_batch
+    pix, src, tgt = synth(B, Ls, Lt, sw.image_size, 32128, dev, seed=1234 + rank)
     images, se, te = {"pixel_values": pix}, {"input_ids": src}, {"input_ids": tgt}
 
     def step():
@@ -159,6 +232,8 @@ def main():
         step()
     eng = core._engine
     eng.probe_enable(True)
+    if ddp is not None:
+        ddp.reducer.reset_stats()
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
@@ -178,45 +253,59 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    launches, probe_ms, flops = eng.probe_read()
+    probes = [eng.probe_read(ch) for ch in (0, 1)]
     eng.probe_enable(False)
     lossv = float(loss.item())
 
     if rank == 0:
+        peak = PEAK_FP8_TFLOPS if a.dtype == "fp8" else PEAK_BF16_TFLOPS
         ms = dt / a.steps * 1e3
         value = world * B * a.steps / dt
         out = {
             "metric": "caption-train samples/sec (224px img, 64-tok tgt)", "value": round(value, 2), "unit": "samples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: Swin-V2(C=64,(2,2,6,2),224,w7) frozen + T5-small, fwd+bwd+Adam, "
-                                   "T5 dropout 0.1 on, random-init weights",
+            "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"{wl['name']}, fwd+bwd+Adam, T5 dropout 0.1 on, random-init weights",
                        "global_batch": world * B, "per_gpu_batch": B, "src_len": Ls, "tgt_len": Lt,
                        "parallelism": f"dp{world}", "hipgraph": bool(core.use_graph),
                        "optimizer": ("klab.optim.FusedAdam (Adam update of ref/train.py:28, one kernel)" if a.optimizer == "klab"
-                                     else "torch.optim.Adam(fused=True)"), "fwd_bwd_gflop_per_sample": GFLOP_PER_SAMPLE["cfg2"],
-                       "step_mfma_frac": round(B * GFLOP_PER_SAMPLE["cfg2"] / (ms * 1e-3) / 1e3 / PEAK_BF16_TFLOPS, 4),
+                                     else "torch.optim.Adam(fused=True)"), "fwd_bwd_gflop_per_sample": wl["gflop"],
+                       "step_mfma_frac": round(B * wl["gflop"] / (ms * 1e-3) / 1e3 / peak, 4),
                        "host_enqueue_ms_per_step": round(host_ms, 3), "final_loss": round(lossv, 4)},
         }
-        if launches > 0:
-            avg_ms = probe_ms / launches
-            ach = flops / (avg_ms * 1e-3) / 1e12
-            traffic = None
-            tp = os.path.join(ROOT, "profiles", "lmhead_traffic.json")
-            if os.path.exists(tp):
-                try:
-                    traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            out["roofline"] = {"kernel": "klab_lmhead_gemm<bf16> (LM-head logits GEMM [B*Lt, 32128] x d=512)", "bound": "mfma",
-                               "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                               "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches": launches,
-                               "flops_per_launch": flops}
+        if ddp is not None:  # evidence that the N > 1 path really reduced over RCCL: ranks and bytes all-reduced per step
+            st = ddp.reducer.stats()
+            out["config"]["rccl"] = {"ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                                     "allreduce_calls_per_step": round(st["calls"] / max(a.steps, 1), 2),
+                                     "allreduce_bytes_per_step": int(st["bytes"] / max(a.steps, 1))}
+        # roofline of the kernels that hold the largest shares of GPU time (profiles/*_kernel_stats.csv): live HIP-event
+        # durations around each launch on the stream it runs on; algorithmic FLOPs = 2*M*N*K per product
+        rl = []
+        names = ["klab_lmhead_gemm<bf16> (LM-head logits GEMM [B*Lt, 32128] x d_model)",
+                 "gemm_glds_grouped_tn_kernel (one grouped launch = all weight-gradient GEMMs of one T5 layer, side stream)"]
+        for ch, (n, tot_ms, fl) in enumerate(probes):
+            if n <= 0 or tot_ms <= 0:
+                continue
+            ach = fl / (tot_ms * 1e-3) / 1e12
+            rl.append({"kernel": names[ch], "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                       "frac": round(ach / peak, 4), "traffic": _traffic("lmhead" if ch == 0 else "grouped_wgrad"),
+                       "avg_launch_ms": round(tot_ms / n, 4), "launches": n, "flops_per_launch": fl / n,
+                       "gpu_time_share_per_step": round(tot_ms / a.steps / ms, 4)})
+        if rl:
+            rl.sort(key=lambda r: -r["gpu_time_share_per_step"])  # dominant (largest share of the step) first
+            out["roofline"] = rl[0]
+            out["roofline"]["whole_step_frac"] = out["config"]["step_mfma_frac"]
+            if len(rl) > 1:
+                out["roofline_secondary"] = rl[1:]
         print(f"[bench] gpu leg done: {value:.1f} samples/s, {ms:.2f} ms/step", file=sys.stderr, flush=True)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if dist_on:
+        del model, core, optimizer, ddp, eng
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 

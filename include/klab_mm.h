@@ -150,6 +150,12 @@ typedef struct klab_swin_attn_args {
   int B, R, w, shift, H, C;
   const void* dctx; void* dqkv; float* dbias; float* dlogit_scale;
   void* bwd_ws; size_t bwd_ws_bytes;
+  /* Windows of more than 64 tokens (384 px / window 24: n = 576), or any window when bias == NULL: the position bias is
+   * looked up per score in bias_table [(2w-1)^2, H] = 16*sigmoid(CPB MLP) (klab_swin_cpb_table) instead of a dense
+   * [H, n, n] tensor (21 MB per block at n = 576, H = 16); backward accumulates d(bias_table) into dbias_table
+   * [(2w-1)^2, H] (zeroed by the caller).  These shapes run tiled kernels (keys streamed in blocks of 64, LDS use
+   * independent of n); lse / dlogit_scale / dqkv as above.                                                         */
+  const float* bias_table; float* dbias_table;
 } klab_swin_attn_args;
 int klab_swin_attn_fwd(const klab_swin_attn_args* a, void* stream);
 /* scratch bytes the matrix-core backward needs for this shape (0: shape outside its envelope) */
@@ -165,6 +171,13 @@ int klab_swin_attn_bwd(const klab_swin_attn_args* a, void* stream);
  * (optional, for backward) are scratch/outputs.                                                 */
 int klab_swin_cpb_bias(const float* coords, const int* index, const float* w0, const float* b0, const float* w2,
                        float* table, float* hidden, float* bias, int ntab, int n, int heads, int nhidden, void* stream);
+/* table form for large windows: table [(2w-1)^2, H] (raw MLP output), hidden (optional), bias_table = 16*sigmoid(table);
+ * backward: d(bias_table) -> MLP weight gradients (accumulated: dw0 [512,2], db0 [512], dw2 [H,512]); dtable is scratch
+ * [(2w-1)^2, H]; any table size, H <= 64.                                                                         */
+int klab_swin_cpb_table(const float* coords, const float* w0, const float* b0, const float* w2, float* table, float* hidden,
+                        float* bias_table, int ntab, int heads, int nhidden, void* stream);
+int klab_swin_cpb_table_bwd(const float* dbias_table, const float* bias_table, const float* coords, const float* hidden, const float* w2,
+                            float* dtable, float* dw0, float* db0, float* dw2, int ntab, int heads, int nhidden, void* stream);
 
 /* ---- input pipeline ---------------------------------------------------------
  * Replaces, for a batch of decoded RGB images, `Image.resize((256,256))` + `ToTensor()` (ref/modules/loader.py:15-16; Pillow
@@ -261,6 +274,16 @@ int klab_engine_param_info(const klab_engine* e, int model, int i, char* name, i
                            long* grad_off /* element offset in the model's flat grad buffer, -1 = frozen */);
 long klab_engine_grad_elems(const klab_engine* e, int model);
 /* backward segment -> (model, offset, length) of the flat-grad slice that is final when it returns */
+/* Gradient buckets INSIDE a backward segment (data parallelism, ref/train.py:26,62: DDP reduces buckets as they become
+ * ready).  Bucket i of a segment = the GEMM-weight gradients of one T5 layer (segments 0, 1) or one Swin block (segment 2),
+ * a contiguous range [off, off+len) of that segment's flat gradient buffer; i counts in the order the backward finishes
+ * them (last layer first).  klab_engine_bucket_wait makes `stream` wait until bucket i of the LAST klab_engine_backward of
+ * that segment is final (an engine-owned event behind the layer's weight-gradient launch); KLAB_ERR_UNSUPPORTED under graph
+ * replay or before any backward.  Everything of the segment outside its buckets is final when klab_engine_backward returns
+ * (on the stream passed to it).                                                                                           */
+int klab_engine_num_buckets(const klab_engine* e, int segment);
+int klab_engine_bucket(const klab_engine* e, int segment, int i, long* off, long* len);
+int klab_engine_bucket_wait(klab_engine* e, int segment, int i, void* stream);
 int klab_engine_segment(const klab_engine* e, int seg, int* model, long* off, long* len);
 size_t klab_engine_workspace_bytes(klab_engine* e, int B, int Ls, int Lt);
 /* *_params: host arrays of device pointers in klab_engine_param_info order.  *_bucket: int32 device
@@ -302,10 +325,12 @@ int klab_adam_step_range(const void* desc_dev, int ndesc, long begin4, long end4
 /* segment 0: LM head + decoder + tied embedding; 1: encoder; 2: Swin (no-op unless train_swin).
  * dloss_dev: device scalar d(objective)/d(loss) (NULL = 1).                                       */
 int klab_engine_backward(klab_engine* e, int segment, const float* dloss_dev, void* stream);
-/* timing probe on the dominant kernel (the LM-head logits GEMM, symbol klab_lmhead_gemm): when enabled, every
- * forward brackets that launch with two HIP events on the compute stream; read back after a synchronize.   */
+/* timing probes: when enabled, selected launches are bracketed by two HIP events ON THE STREAM THEY ARE LAUNCHED ON; read back
+ * after a synchronize.  channel 0: the LM-head logits GEMM of every forward (symbol klab_lmhead_gemm, compute stream);
+ * channel 1: every grouped weight-gradient launch of the T5 backward (symbol gemm_glds_grouped_tn_kernel, the engine's side
+ * stream).  probe_read returns the launch count, the summed duration and the summed algorithmic FLOPs (2*M*N*K) of a channel. */
 int klab_engine_probe_enable(klab_engine* e, int on);
-int klab_engine_probe_read(klab_engine* e, int* launches, float* total_ms, double* flops_per_launch);
+int klab_engine_probe_read(klab_engine* e, int channel, int* launches, float* total_ms, double* flops_total);
 const float* klab_engine_loss_ptr(const klab_engine* e);
 const int* klab_engine_err_ptr(const klab_engine* e);
 /* device words {seed of the current step, base seed, forwards since seeding} (for stream-ordered snapshots; see klab_engine_get_rng) */

@@ -41,7 +41,7 @@ class SwinAttnArgs(C.Structure):
     _fields_ = [("dtype", i32), ("qkv", vp), ("ctx", vp), ("bias", vp), ("logit_scale", vp), ("lse", vp),
                 ("B", i32), ("R", i32), ("w", i32), ("shift", i32), ("H", i32), ("C", i32),
                 ("dctx", vp), ("dqkv", vp), ("dbias", vp), ("dlogit_scale", vp),
-                ("bwd_ws", vp), ("bwd_ws_bytes", C.c_size_t)]
+                ("bwd_ws", vp), ("bwd_ws_bytes", C.c_size_t), ("bias_table", vp), ("dbias_table", vp)]
 
 
 # every exported entry point of include/klab_mm.h: name -> argtypes (restype is always int)
@@ -68,6 +68,8 @@ SIGNATURES = {
     "klab_swin_attn_bwd": [C.POINTER(SwinAttnArgs), vp],
     "klab_swin_attn_bwd_ws_bytes": [i32, i32, i32, i32, i32, i32],
     "klab_swin_cpb_bias": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "klab_swin_cpb_table": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "klab_swin_cpb_table_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "klab_cast_pack": [vp, i32, i64, vp, i32, vp],
     "klab_embed_fwd": [vp, i32, i32, i32, i32, vp, i32, vp, i32, i32, f32, vp, u32, vp, vp],
     "klab_embed_bwd": [vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, f32, vp, u32, vp],

@@ -908,8 +908,22 @@ static int launch_swin_bwd(const SwinAttnP& p, hipStream_t s) {
   return KLAB_OK;
 }
 
+namespace klab {
+int swin_attn_large_dispatch(const klab_swin_attn_args* a, bool backward, hipStream_t s);  // attn_swin_large.hip
+int cpb_mlp_bwd_any_launch(const float* dtable, const float* coords, const float* hidden, const float* w2, float* dw0, float* db0,
+                           float* dw2, int ntab, int heads, int nhidden, hipStream_t s);
+int cpb_table_launch(const float* coords, const float* w0, const float* b0, const float* w2, float* table, float* hidden, int ntab,
+                     int heads, int nhidden, hipStream_t s) {
+  hipLaunchKernelGGL(cpb_table_kernel, dim3(ntab), dim3(256), 0, s, coords, w0, b0, w2, table, hidden, heads, nhidden);
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+}  // namespace klab
+// windows of more than 64 tokens, or a bias supplied as the (2w-1)^2 x H table: the tiled kernels of attn_swin_large.hip
+static bool swin_use_large(const klab_swin_attn_args* a) { return a->w * a->w > 64 || (!a->bias && a->bias_table); }
+
 static int swin_args_ok(const klab_swin_attn_args* a) {
-  if (!a || !a->qkv || !a->ctx || !a->bias || !a->logit_scale) return KLAB_ERR_BADARG;
+  if (!a || !a->qkv || !a->ctx || (!a->bias && !a->bias_table) || !a->logit_scale) return KLAB_ERR_BADARG;
   if (a->w <= 0 || a->R % a->w) return KLAB_ERR_UNSUPPORTED;  // padded windows (HF/swinv2:645-650) are out of scope
   if (a->C % a->H) return KLAB_ERR_BADARG;
   if (a->shift < 0 || a->shift >= a->w) return KLAB_ERR_BADARG;
@@ -919,6 +933,7 @@ static int swin_args_ok(const klab_swin_attn_args* a) {
 extern "C" int klab_swin_attn_fwd(const klab_swin_attn_args* a, void* stream) {
   int rc = swin_args_ok(a);
   if (rc) return rc;
+  if (swin_use_large(a)) return swin_attn_large_dispatch(a, false, (hipStream_t)stream);
   SwinAttnP p{a->qkv, a->ctx, a->bias, a->logit_scale, a->lse, a->B, a->R, a->w, a->shift, a->H, a->C, nullptr, nullptr, nullptr, nullptr};
   const int hd = a->C / a->H;
   hipStream_t s = (hipStream_t)stream;
@@ -986,6 +1001,7 @@ extern "C" int klab_swin_attn_bwd(const klab_swin_attn_args* a, void* stream) {
   int rc = swin_args_ok(a);
   if (rc) return rc;
   if (!a->dctx || !a->dqkv || !a->lse) return KLAB_ERR_BADARG;
+  if (swin_use_large(a)) return swin_attn_large_dispatch(a, true, (hipStream_t)stream);
   SwinAttnP p{a->qkv, a->ctx, a->bias, a->logit_scale, a->lse, a->B, a->R, a->w, a->shift, a->H, a->C,
               a->dctx, a->dqkv, a->dbias, a->dlogit_scale};
   const int hd = a->C / a->H;
@@ -1026,7 +1042,8 @@ extern "C" int klab_swin_cpb_bias_bwd(const float* dbias, const float* bias, con
   const long tot = (long)heads * n * n;
   hipLaunchKernelGGL(cpb_dtable_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, dbias, bias, index, dtable, heads, n * n);
   KLAB_LAUNCH_CHECK();
-  if (ntab > 192) return KLAB_ERR_UNSUPPORTED;  // windows above 7x7 are out of scope
+  if (ntab > 192)  // windows above 7x7 (8x8: 225 table rows): the any-size form
+    return cpb_mlp_bwd_any_launch(dtable, coords, hidden, w2, dw0, db0, dw2, ntab, heads, nhidden, s);
   const size_t cpb_lds = ((size_t)ntab * heads + (size_t)(heads > 3 ? heads : 3) * 16 * 17) * 4;
   if (cpb_lds > 64 * 1024) return KLAB_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(cpb_mlp_bwd_kernel, dim3((nhidden + 15) / 16), dim3(256), cpb_lds, s, dtable, coords, hidden, w2, dw0, db0, dw2, ntab, heads, nhidden);

@@ -64,6 +64,7 @@ struct SwinBlockBufs {
   void *qkv, *ctx, *po; float *lse, *mean1, *rstd1; float* h1; void* h1t;
   void *z, *a, *fo; float *mean2, *rstd2; float* h2; void* h2t;
   float *bias, *table, *hidden;
+  float* btab;  // windows of more than 64 tokens: 16*sigmoid(table) [(2w-1)^2, H], looked up per score (no dense bias)
   int R, w, shift, H, C; long M;
 };
 struct SwinStageBufs { std::vector<SwinBlockBufs> blk; void *mg, *mo; float *mmean, *mrstd; float* xm; void* xmt; };
@@ -90,6 +91,13 @@ struct klab_engine {
   long seg_off[3] = {0, 0, 0}, seg_len[3] = {0, 0, 0};            // per segment: extent in its flat grad buffer
   long warena_elems = 0, farena_elems = 0;
   long kvall_w_off = -1, kvall_g_off = -1;  // decoder cross k|v of all layers (weight arena / grad offsets)
+  // gradient buckets inside a backward segment, in the order they become final: one per T5 layer (its GEMM weights are
+  // adjacent in the flat buffer; final when the layer's grouped weight-gradient launch has run on the side stream), one per
+  // Swin block.  The data-parallel reducer all-reduces bucket i behind bucket_ev[seg][i] while the rest of the segment runs.
+  struct Bucket { long off, len; };
+  std::vector<Bucket> buckets[3];
+  std::vector<hipEvent_t> bucket_ev[3];
+  bool bucket_ev_live[3] = {false, false, false};  // recorded by the last backward of that segment (never under graph replay)
   int pe_k0 = 0, pe_kp = 0;  // patch-embedding weight rows: K0 = in_ch*patch^2 values, stored at a pitch of pe_kp (zero-padded)
   // ---- bound state ----
   bool bound = false;
@@ -124,7 +132,7 @@ struct klab_engine {
   // swin backward scratch
   float *sdh_a = nullptr, *sdh_b = nullptr, *sdm = nullptr; void *sdy = nullptr, *sdctx = nullptr, *sdqkv = nullptr, *sda = nullptr;
   void* sattn_ws = nullptr; size_t sattn_ws_bytes = 0;
-  float *sdbias = nullptr, *sdtable = nullptr;
+  float *sdbias = nullptr, *sdtable = nullptr, *sdbtab = nullptr;
   // side stream: independent chains run beside the main one (frozen language encoder || Swin; weight gradients ||
   // the activation-gradient chain); joined back with events before anything the caller can observe
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -140,8 +148,10 @@ struct klab_engine {
   float* pixels_buf = nullptr; long long *src_buf = nullptr, *tgt_buf = nullptr; float* dloss_buf = nullptr;
   const float* pixels_cur = nullptr;  // what this forward's patch embedding reads: the caller's tensor, or pixels_buf under graph replay
   uint32_t seed_base = 0; bool seed_set = false;
-  // probe: HIP events around the LM-head GEMM of each forward
-  bool probe_on = false; std::vector<hipEvent_t> ev0, ev1; int probe_n = 0;
+  // probes: HIP events around selected launches, on the stream they are launched on.  Channel 0: the LM-head logits GEMM of
+  // each forward; channel 1: every grouped weight-gradient launch of the T5 backward (side stream)
+  bool probe_on = false;
+  struct Probe { std::vector<hipEvent_t> a, b; std::vector<double> flops; int n = 0; } probe[2];
   float p_train = 0.f;   // dropout prob in effect for the last forward (0 in eval)
   const long long* last_tgt = nullptr;
 };
@@ -302,7 +312,13 @@ void plan_grads(klab_engine* e) {
     put(e->mi.dec_final);
     e->seg_zero_len[0] = g;
     put(e->mi.shared);
-    for (auto& l : e->mi.dec) { put(l.q); put(l.k); put(l.v); put(l.o); put(l.cq); put(l.co); put(l.wi); put(l.wo); }
+    e->buckets[0].assign(e->mi.dec.size(), klab_engine::Bucket{0, 0});
+    for (size_t li = 0; li < e->mi.dec.size(); ++li) {
+      auto& l = e->mi.dec[li];
+      const long g0 = g;
+      put(l.q); put(l.k); put(l.v); put(l.o); put(l.cq); put(l.co); put(l.wi); put(l.wo);
+      e->buckets[0][e->mi.dec.size() - 1 - li] = klab_engine::Bucket{g0, g - g0};  // backward visits the last layer first
+    }
     e->kvall_g_off = g;
     for (auto& l : e->mi.dec) { put(l.ck); put(l.cv); }
     e->seg_len[0] = g;
@@ -310,7 +326,13 @@ void plan_grads(klab_engine* e) {
     for (auto& l : e->mi.enc) { put(l.ln0); put(l.ln2); put(l.relb); }
     put(e->mi.enc_final);
     e->seg_zero_len[1] = g - e->seg_off[1];
-    for (auto& l : e->mi.enc) { put(l.q); put(l.k); put(l.v); put(l.o); put(l.wi); put(l.wo); }
+    e->buckets[1].assign(e->mi.enc.size(), klab_engine::Bucket{0, 0});
+    for (size_t li = 0; li < e->mi.enc.size(); ++li) {
+      auto& l = e->mi.enc[li];
+      const long g0 = g;
+      put(l.q); put(l.k); put(l.v); put(l.o); put(l.wi); put(l.wo);
+      e->buckets[1][e->mi.enc.size() - 1 - li] = klab_engine::Bucket{g0, g - g0};
+    }
     e->seg_len[1] = g - e->seg_off[1];
     e->grad_elems[2] = g;
   }
@@ -328,10 +350,16 @@ void plan_grads(klab_engine* e) {
     }
     e->seg_zero_off[2] = 0; e->seg_zero_len[2] = g;
     put(e->si.pew);
+    std::vector<klab_engine::Bucket> fwd_order;
     for (auto& st : e->si.st) {
-      for (auto& k : st.blk) { put(k.qw); put(k.kw); put(k.vw); put(k.pw); put(k.f1w); put(k.f2w); }
+      for (auto& k : st.blk) {
+        const long g0 = g;
+        put(k.qw); put(k.kw); put(k.vw); put(k.pw); put(k.f1w); put(k.f2w);
+        fwd_order.push_back(klab_engine::Bucket{g0, g - g0});
+      }
       put(st.redw);
     }
+    e->buckets[2].assign(fwd_order.rbegin(), fwd_order.rend());
     e->seg_off[2] = 0; e->seg_len[2] = g;
     e->grad_elems[0] = g;
   }
@@ -475,7 +503,10 @@ size_t plan_workspace(klab_engine* e, void* base, int B, int Ls, int Lt) {
       q.a = b.take((size_t)M * F * es); q.fo = b.take((size_t)M * C * es);
       q.mean2 = (float*)b.take((size_t)M * 4); q.rstd2 = (float*)b.take((size_t)M * 4);
       q.h2 = (float*)b.take((size_t)M * C * 4); q.h2t = b.take((size_t)M * C * es);
-      q.bias = (float*)b.take((size_t)H * n * n * 4); q.table = (float*)b.take((size_t)ntab * H * 4);
+      const bool big = n > 64;  // tiled attention kernels with the bias as a table (attn_swin_large.hip)
+      q.bias = big ? nullptr : (float*)b.take((size_t)H * n * n * 4);
+      q.btab = big ? (float*)b.take((size_t)ntab * H * 4) : nullptr;
+      q.table = (float*)b.take((size_t)ntab * H * 4);
       q.hidden = (float*)b.take((size_t)ntab * 512 * 4);
     }
     sb.mg = sb.mo = nullptr; sb.mmean = sb.mrstd = nullptr; sb.xm = nullptr; sb.xmt = nullptr;
@@ -494,13 +525,15 @@ size_t plan_workspace(klab_engine* e, void* base, int B, int Ls, int Lt) {
     e->sdm = (float*)b.take((size_t)maxMC * 4);
     e->sdy = b.take((size_t)maxMC * es); e->sdctx = b.take((size_t)maxMC * es);
     e->sdqkv = b.take((size_t)maxMC * 3 * es); e->sda = b.take((size_t)maxMC * F0 * es);
-    int maxn = 0, maxH = 0;
+    int maxn = 0, maxH = 0, maxn_small = 1;
     for (int st = 0; st < s.n_stages; ++st) {
       const int R = R0 >> st; const int w = R < s.window ? R : s.window;
       if (w * w > maxn) maxn = w * w;
+      if (w * w <= 64 && w * w > maxn_small) maxn_small = w * w;
       if (s.heads[st] > maxH) maxH = s.heads[st];
     }
-    e->sdbias = (float*)b.take((size_t)maxH * maxn * maxn * 4);
+    e->sdbias = (float*)b.take((size_t)maxH * maxn_small * maxn_small * 4);  // dense d(bias) of the one-tile windows
+    e->sdbtab = (float*)b.take((size_t)(4 * maxn) * maxH * 4);               // d(bias table) of the large windows
     e->sdtable = (float*)b.take((size_t)(4 * maxn) * maxH * 4 + (size_t)(4 * maxn) * 512 * 4);
     e->sattn_ws = nullptr; e->sattn_ws_bytes = 0;
     const char* ev = getenv("KLAB_SWIN_BWD_MFMA");  // "0": keep the vector-ALU window-attention backward (A/B switch)
@@ -509,8 +542,7 @@ size_t plan_workspace(klab_engine* e, void* base, int B, int Ls, int Lt) {
       for (int st = 0; st < s.n_stages; ++st) {
         const int R = R0 >> st; const int w = R < s.window ? R : s.window;
         const size_t x = klab_swin_attn_bwd_ws_bytes(c.dtype, B, R, w, s.heads[st], s.embed_dim << st);
-        if (x == 0) { need = 0; break; }
-        if (x > need) need = x;
+        if (x > need) need = x;  // (0: that stage is outside the matrix-core envelope and runs its own kernels)
       }
       if (need) { e->sattn_ws = b.take(need); e->sattn_ws_bytes = need; }
     }
@@ -657,7 +689,16 @@ struct WgradQueue {
       g.accumulate = 1; g.atomic_ok = 1;
       gs.push_back(g);
     }
+    klab_engine::Probe& pr = c.e->probe[1];
+    const bool probe = c.e->probe_on && pr.n < (int)pr.a.size();
+    if (probe) RC((int)hipEventRecord(pr.a[pr.n], cs.s));
     RC(klab_gemm_grouped(gs.data(), (int)gs.size(), cs.ws()));
+    if (probe) {
+      RC((int)hipEventRecord(pr.b[pr.n], cs.s));
+      double fl = 0;
+      for (const PendingWgrad& w : q) fl += 2.0 * w.M * (double)w.N * w.K;
+      pr.flops[pr.n++] = fl;
+    }
     q.clear();
     return 0;
   }
@@ -777,6 +818,13 @@ int t5_stack_backward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Pa
       float* t = dh_cur; dh_cur = dh_oth; dh_oth = t;
     }
     RC(wq.flush(c));  // this layer's weight gradients: one event, then they overlap the next layer's chain
+    {  // the layer's bucket of the flat gradient buffer is final behind this point of the side stream
+      const int seg = dec ? 0 : 1, bi = (int)L.size() - 1 - i;
+      if (Gflat == e->G[2] && !e->use_graph && bi < (int)e->bucket_ev[seg].size()) {
+        RC((int)hipEventRecord(e->bucket_ev[seg][bi], e->side));
+        if (i == 0) e->bucket_ev_live[seg] = true;
+      }
+    }
   }
   if (part_ok && rms_calls) {
     if (rms_calls != e->rms_ncalls[stk]) return KLAB_ERR_BADARG;  // the destination table was built for exactly this visiting order
@@ -820,14 +868,19 @@ int swin_forward(const Ctx& c, const float* pixels, float p_in, bool refresh_bia
       const SwinBlockIdx& ix = e->si.st[st].blk[k];
       const int C = q.C, M = (int)q.M, F = s.mlp_ratio * C, n = q.w * q.w;
       q.x_in = x; q.xt_in = xt;
-      if (refresh_bias)  // input-independent: with a frozen Swin the 16*sigmoid(CPB) tables are computed once per weight version
-        RC(klab_swin_cpb_bias(e->swin_coords[st], e->swin_index[st], W[ix.c0w], W[ix.c0b], W[ix.c2w], q.table, q.hidden, q.bias,
-                              e->swin_ntab[st], n, q.H, 512, c.ws()));
+      if (refresh_bias) {  // input-independent: with a frozen Swin the 16*sigmoid(CPB) tables are computed once per weight version
+        if (q.btab)
+          RC(klab_swin_cpb_table(e->swin_coords[st], W[ix.c0w], W[ix.c0b], W[ix.c2w], q.table, q.hidden, q.btab, e->swin_ntab[st], q.H, 512,
+                                 c.ws()));
+        else
+          RC(klab_swin_cpb_bias(e->swin_coords[st], e->swin_index[st], W[ix.c0w], W[ix.c0b], W[ix.c2w], q.table, q.hidden, q.bias,
+                                e->swin_ntab[st], n, q.H, 512, c.ws()));
+      }
       const float* qkvb = ix.qb >= 0 ? e->farena + bias_off : nullptr;
       bias_off += 3 * C;
       static const bool fused_qkv = [] { const char* v = getenv("KLAB_SWIN_FUSED_QKV"); return !v || atoi(v) != 0; }();
       int qrc = KLAB_ERR_UNSUPPORTED;
-      if (!e->cfg.train_swin && fused_qkv)  // frozen tower, narrow stage: q|k|v never leave the chip
+      if (!e->cfg.train_swin && fused_qkv && q.bias)  // frozen tower, narrow stage, one-tile window: q|k|v never leave the chip
         qrc = klab_swin_qkv_attn_fused(xt, woff(c, P[ix.qw].warena_off), qkvb, q.ctx, q.bias, W[ix.ls], c.dt, B, q.R, q.w, q.shift, q.H, C,
                                        c.ws());
       if (qrc != 0 && qrc != KLAB_ERR_UNSUPPORTED) return qrc;
@@ -835,7 +888,7 @@ int swin_forward(const Ctx& c, const float* pixels, float p_in, bool refresh_bia
         RC(linear_fwd(c, xt, M, C, P[ix.qw].warena_off, 3 * C, q.qkv, 3 * C, c.dt, qkvb));
         klab_swin_attn_args a;
         memset(&a, 0, sizeof(a));
-        a.dtype = c.dt; a.qkv = q.qkv; a.ctx = q.ctx; a.bias = q.bias; a.logit_scale = W[ix.ls]; a.lse = q.lse;
+        a.dtype = c.dt; a.qkv = q.qkv; a.ctx = q.ctx; a.bias = q.bias; a.bias_table = q.btab; a.logit_scale = W[ix.ls]; a.lse = q.lse;
         a.B = B; a.R = q.R; a.w = q.w; a.shift = q.shift; a.H = q.H; a.C = C;
         RC(klab_swin_attn_fwd(&a, c.ws()));
       }
@@ -928,8 +981,11 @@ extern "C" void klab_engine_destroy(klab_engine* e) {
   if (e->ev_in) hipEventDestroy(e->ev_in);
   if (e->ev_out) hipEventDestroy(e->ev_out);
   for (auto ev : e->evpool) if (ev) hipEventDestroy(ev);
-  for (auto ev : e->ev0) if (ev) hipEventDestroy(ev);
-  for (auto ev : e->ev1) if (ev) hipEventDestroy(ev);
+  for (auto& v : e->bucket_ev) for (auto ev : v) if (ev) hipEventDestroy(ev);
+  for (auto& pr : e->probe) {
+    for (auto ev : pr.a) if (ev) hipEventDestroy(ev);
+    for (auto ev : pr.b) if (ev) hipEventDestroy(ev);
+  }
   if (e->side) hipStreamDestroy(e->side);  // streams last: every event recorded on them is gone
   if (e->own) hipStreamDestroy(e->own);
   delete e;
@@ -959,6 +1015,22 @@ extern "C" int klab_engine_segment(const klab_engine* e, int seg, int* model, lo
   if (off) *off = e->seg_off[seg];
   if (len) *len = e->seg_len[seg];
   return 0;
+}
+
+extern "C" int klab_engine_num_buckets(const klab_engine* e, int segment) {
+  if (!e || segment < 0 || segment > 2) return -1;
+  return (int)e->buckets[segment].size();
+}
+extern "C" int klab_engine_bucket(const klab_engine* e, int segment, int i, long* off, long* len) {
+  if (!e || segment < 0 || segment > 2 || i < 0 || i >= (int)e->buckets[segment].size()) return KLAB_ERR_BADARG;
+  if (off) *off = e->buckets[segment][i].off;
+  if (len) *len = e->buckets[segment][i].len;
+  return KLAB_OK;
+}
+extern "C" int klab_engine_bucket_wait(klab_engine* e, int segment, int i, void* stream) {
+  if (!e || !e->bound || segment < 0 || segment > 2 || i < 0 || i >= (int)e->bucket_ev[segment].size()) return KLAB_ERR_BADARG;
+  if (!e->bucket_ev_live[segment]) return KLAB_ERR_UNSUPPORTED;  // graph replay, or no backward of that segment yet
+  return (int)hipStreamWaitEvent((hipStream_t)stream, e->bucket_ev[segment][i], 0);
 }
 
 extern "C" size_t klab_engine_workspace_bytes(klab_engine* e, int B, int Ls, int Lt) {
@@ -1118,7 +1190,12 @@ extern "C" int klab_engine_bind(klab_engine* e, int B, int Ls, int Lt, void* wor
     for (auto& ev : e->evpool) RC((int)hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     RC((int)hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
     RC((int)hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming));
+    for (int sg = 0; sg < 3; ++sg) {
+      e->bucket_ev[sg].assign(e->buckets[sg].size(), nullptr);
+      for (auto& ev : e->bucket_ev[sg]) RC((int)hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
   }
+  for (int sg = 0; sg < 3; ++sg) e->bucket_ev_live[sg] = false;
   e->bound = true;
   return 0;
 }
@@ -1312,10 +1389,11 @@ extern "C" int klab_engine_forward(klab_engine* e, const float* pixels, const lo
     g.alpha = cfg.main.scale_decoder_outputs ? 1.f / sqrtf((float)d) : 1.f;  // HF/t5:1044-1045
     g.name_tag = 1;
     // the LM-head launch stays outside the graphs so that the probe's HIP events can bracket it
-    const bool probe = e->probe_on && e->probe_n < (int)e->ev0.size();
-    if (probe) RC((int)hipEventRecord(e->ev0[e->probe_n], c.s));
+    klab_engine::Probe& pr = e->probe[0];
+    const bool probe = e->probe_on && pr.n < (int)pr.a.size();
+    if (probe) RC((int)hipEventRecord(pr.a[pr.n], c.s));
     RC(klab_gemm(&g, c.ws()));
-    if (probe) { RC((int)hipEventRecord(e->ev1[e->probe_n], c.s)); ++e->probe_n; }
+    if (probe) { RC((int)hipEventRecord(pr.b[pr.n], c.s)); pr.flops[pr.n++] = 2.0 * Md * (double)V * d; }
     RC(run_graphed(e, want_grad ? 3 : 2, c.s, [&]() {
       return klab_ce_fwd(e->logits, V, c.dt, e->tgt_buf, Md, V, e->inv_n, e->loss_row, e->loss, want_grad, c.ws());
     }));
@@ -1325,28 +1403,34 @@ extern "C" int klab_engine_forward(klab_engine* e, const float* pixels, const lo
 
 extern "C" int klab_engine_probe_enable(klab_engine* e, int on) {
   if (!e) return KLAB_ERR_BADARG;
-  if (on && e->ev0.empty()) {
-    e->ev0.resize(512); e->ev1.resize(512);
-    for (size_t i = 0; i < e->ev0.size(); ++i) {
-      if (hipEventCreate(&e->ev0[i]) != hipSuccess || hipEventCreate(&e->ev1[i]) != hipSuccess) return KLAB_ERR_UNSUPPORTED;
+  if (on && e->probe[0].a.empty()) {
+    const size_t cap[2] = {1024, 16384};
+    for (int ch = 0; ch < 2; ++ch) {
+      klab_engine::Probe& pr = e->probe[ch];
+      pr.a.assign(cap[ch], nullptr); pr.b.assign(cap[ch], nullptr); pr.flops.assign(cap[ch], 0.0);
+      for (size_t i = 0; i < cap[ch]; ++i)
+        if (hipEventCreate(&pr.a[i]) != hipSuccess || hipEventCreate(&pr.b[i]) != hipSuccess) return KLAB_ERR_UNSUPPORTED;
     }
   }
   e->probe_on = on != 0;
-  e->probe_n = 0;
+  if (on) for (auto& pr : e->probe) pr.n = 0;
   return 0;
 }
-extern "C" int klab_engine_probe_read(klab_engine* e, int* launches, float* total_ms, double* flops_per_launch) {
-  if (!e) return KLAB_ERR_BADARG;
+extern "C" int klab_engine_probe_read(klab_engine* e, int channel, int* launches, float* total_ms, double* flops_total) {
+  if (!e || channel < 0 || channel > 1) return KLAB_ERR_BADARG;
+  klab_engine::Probe& pr = e->probe[channel];
   float tot = 0.f;
-  for (int i = 0; i < e->probe_n; ++i) {
+  double fl = 0;
+  for (int i = 0; i < pr.n; ++i) {
     float ms = 0.f;
-    hipError_t er = hipEventElapsedTime(&ms, e->ev0[i], e->ev1[i]);
+    hipError_t er = hipEventElapsedTime(&ms, pr.a[i], pr.b[i]);
     if (er != hipSuccess) return (int)er;
     tot += ms;
+    fl += pr.flops[i];
   }
-  if (launches) *launches = e->probe_n;
+  if (launches) *launches = pr.n;
   if (total_ms) *total_ms = tot;
-  if (flops_per_launch) *flops_per_launch = 2.0 * (double)e->B * e->Lt * (double)e->cfg.main.vocab * (double)e->cfg.main.d_model;
+  if (flops_total) *flops_total = fl;
   return 0;
 }
 extern "C" const float* klab_engine_loss_ptr(const klab_engine* e) { return e ? e->loss : nullptr; }
@@ -1371,6 +1455,7 @@ static int backward_segment(klab_engine* e, int segment, const float* dloss_dev,
   const int B = e->B, d = cfg.main.d_model, inner = cfg.main.n_heads * cfg.main.d_kv, nld = cfg.main.n_dec_layers;
   const float p = e->p_train;
   float* Gm = e->G[2];
+  e->bucket_ev_live[segment] = false;
   if (segment == 0) {
     e->ev_next = 0;
     RC((int)hipMemsetAsync(Gm + e->seg_off[0], 0, (size_t)e->seg_len[0] * 4, c.s));
@@ -1464,6 +1549,7 @@ int swin_backward(const Ctx& c, const float* dh0, float p_in) {
   for (int st = 0; st < s.n_stages; ++st) bias_off_total += 3L * (C0 << st) * s.depths[st];
   long bias_off = bias_off_total;
   (void)bias_off;
+  int swin_bucket = 0;
   for (int st = last; st >= 0; --st) {
     SwinStageBufs& sb = e->sw[st];
     const int R = R0 >> st, C = C0 << st;
@@ -1502,21 +1588,33 @@ int swin_backward(const Ctx& c, const float* dh0, float p_in) {
       RC(klab_colsum(e->sdy, C, c.dt, M, C, G(ix.pb), c.ws()));
       RC(linear_wgrad(c, e->sdy, C, q.ctx, C, M, C, C, G(ix.pw)));
       RC(linear_dgrad(c, e->sdy, C, M, C, P[ix.pw].warena_off, C, e->sdctx, c.dt));
-      RC((int)hipMemsetAsync(e->sdbias, 0, (size_t)q.H * n * n * 4, c.s));
       klab_swin_attn_args a;
       memset(&a, 0, sizeof(a));
-      a.dtype = c.dt; a.qkv = q.qkv; a.ctx = q.ctx; a.bias = q.bias; a.logit_scale = W[ix.ls]; a.lse = q.lse;
+      a.dtype = c.dt; a.qkv = q.qkv; a.ctx = q.ctx; a.bias = q.bias; a.bias_table = q.btab; a.logit_scale = W[ix.ls]; a.lse = q.lse;
       a.B = B; a.R = q.R; a.w = q.w; a.shift = q.shift; a.H = q.H; a.C = C;
-      a.dctx = e->sdctx; a.dqkv = e->sdqkv; a.dbias = e->sdbias; a.dlogit_scale = G(ix.ls);
+      a.dctx = e->sdctx; a.dqkv = e->sdqkv; a.dlogit_scale = G(ix.ls);
       a.bwd_ws = e->sattn_ws; a.bwd_ws_bytes = e->sattn_ws_bytes;
-      RC(klab_swin_attn_bwd(&a, c.ws()));
-      RC(klab_swin_cpb_bias_bwd(e->sdbias, q.bias, e->swin_index[st], e->swin_coords[st], q.hidden, W[ix.c0w], W[ix.c2w], e->sdtable, G(ix.c0w),
-                                G(ix.c0b), G(ix.c2w), e->swin_ntab[st], n, q.H, 512, c.ws()));
+      if (q.btab) {  // large window: the bias gradient is accumulated per table entry
+        RC((int)hipMemsetAsync(e->sdbtab, 0, (size_t)e->swin_ntab[st] * q.H * 4, c.s));
+        a.dbias_table = e->sdbtab;
+        RC(klab_swin_attn_bwd(&a, c.ws()));
+        RC(klab_swin_cpb_table_bwd(e->sdbtab, q.btab, e->swin_coords[st], q.hidden, W[ix.c2w], e->sdtable, G(ix.c0w), G(ix.c0b), G(ix.c2w),
+                                   e->swin_ntab[st], q.H, 512, c.ws()));
+      } else {
+        RC((int)hipMemsetAsync(e->sdbias, 0, (size_t)q.H * n * n * 4, c.s));
+        a.dbias = e->sdbias;
+        RC(klab_swin_attn_bwd(&a, c.ws()));
+        RC(klab_swin_cpb_bias_bwd(e->sdbias, q.bias, e->swin_index[st], e->swin_coords[st], q.hidden, W[ix.c0w], W[ix.c2w], e->sdtable,
+                                  G(ix.c0w), G(ix.c0b), G(ix.c2w), e->swin_ntab[st], n, q.H, 512, c.ws()));
+      }
       if (ix.qb >= 0) {
         RC(klab_colsum(e->sdqkv, 3 * C, c.dt, M, C, G(ix.qb), c.ws()));
         RC(klab_colsum((char*)e->sdqkv + (size_t)2 * C * c.es, 3 * C, c.dt, M, C, G(ix.vb), c.ws()));
       }
       RC(linear_wgrad(c, e->sdqkv, 3 * C, q.xt_in, C, M, 3 * C, C, G(ix.qw)));  // q|k|v grads adjacent
+      if (!e->use_graph && swin_bucket < (int)e->bucket_ev[2].size())  // this block's GEMM-weight gradients are final
+        RC((int)hipEventRecord(e->bucket_ev[2][swin_bucket], c.s));
+      ++swin_bucket;
       {
         klab_gemm_args g = G0(c, M, C, 3 * C, e->sdqkv, 3 * C, 1, woff(c, P[ix.qw].warena_off), C, 0, dh, C, KLAB_F32);
         g.accumulate = 1;
@@ -1531,6 +1629,7 @@ int swin_backward(const Ctx& c, const float* dh0, float p_in) {
                         0.f, nullptr, 0, c.ws()));
   RC(klab_colsum(e->sdy, C0, c.dt, (int)M0, C0, G(e->si.peb), c.ws()));
   RC(linear_wgrad(c, e->sdy, C0, e->cols, e->pe_kp, (int)M0, C0, K0, G(e->si.pew)));
+  e->bucket_ev_live[2] = !e->use_graph;
   return 0;
 }
 

@@ -18,51 +18,108 @@ from torch import nn
 
 
 class SegmentReducer:
-    """All-reduce (mean) of slices of flat gradient buffers, asynchronously, in launch order.
+    """All-reduce (mean) of slices of flat gradient buffers, asynchronously, in the order the backward finishes them.
 
-    Device-agnostic so that the bucket logic is testable with gloo on CPU; on GPU the collective runs
-    on `comm_stream` behind an event recorded on the compute stream."""
+    A segment is reduced as (1) its layer buckets -- contiguous ranges the engine finishes one after the other, each behind its
+    own engine-owned event, merged until a message is at least `min_bucket_elems` long (xGMI: per-peer slices of a direct
+    reduce-scatter must stay bandwidth-bound) -- and (2) the remainder of the segment (norm weights, the tied
+    embedding, the cross-attention k|v block), which is final when the segment's backward has been enqueued.  The host issues
+    all of a segment's collectives right after enqueueing it; on the GPU each one starts when ITS event fires, i.e. while
+    the later layers of the same segment are still running (torch DDP's bucket-ready overlap, TORCH/ddp:1229-1250).
 
-    def __init__(self, segments: List[Tuple[str, int, int]], process_group=None, max_bucket_elems: int = 64 << 20):
+    Device-agnostic so that the bucket logic is testable with gloo on CPU; on GPU the collectives run on `comm_stream`."""
+
+    def __init__(self, segments: List[Tuple[str, int, int]], process_group=None, max_bucket_elems: int = 64 << 20,
+                 engine=None, min_bucket_elems: int = 6 << 20):
         self.segments = segments
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.max_bucket = max_bucket_elems
+        self.min_bucket = min_bucket_elems
+        self.engine = engine  # provides .buckets[seg] = [(off, len)] in ready order and .bucket_wait(seg, i, stream)
         self.comm_stream: Optional[torch.cuda.Stream] = None
         self._works = []
         self._seg_events = {}  # segment -> event recorded on the comm stream behind that segment's last all-reduce
         backend = dist.get_backend(process_group) if dist.is_initialized() else ""
         self._avg_op = dist.ReduceOp.AVG if backend == "nccl" else None
+        self._calls = 0
+        self._bytes = 0
+        self.last_plan = []  # [(segment, model, offset, length, waits_on_bucket | None)] of the last reduce_segment calls (tests)
+
+    def reset_stats(self):
+        self._calls = self._bytes = 0
+
+    def stats(self):
+        return {"calls": self._calls, "bytes": self._bytes}
 
     def world_active(self):
         return self.world > 1 or (dist.is_initialized() and os.environ.get("KLAB_DDP_FORCE_COLLECTIVE") == "1")
 
-    def buckets(self, seg: int):
-        """(model, offset, length) pieces of a segment: large segments are cut so that RCCL can start
-        on the first piece while the rest is still being enqueued/transferred."""
-        model, off, ln = self.segments[seg]
+    def _cut(self, model, off, ln, wait):
         out = []
         while ln > 0:
             n = min(ln, self.max_bucket)
-            out.append((model, off, n))
+            out.append((model, off, n, wait))
             off += n
             ln -= n
         return out
 
-    def reduce_segment(self, seg: int, flats):
+    def plan(self, seg: int):
+        """[(model, offset, length, wait)] messages of a segment in issue order.  wait = index of the engine bucket whose event
+        the message waits for, or None = wait for the whole segment (the caller's stream)."""
+        model, off, ln = self.segments[seg]
+        layer = list(self.engine.buckets[seg]) if self.engine is not None and seg < len(self.engine.buckets) else []
+        msgs, covered = [], []
+        i = 0
+        while i < len(layer):  # merge consecutive ready buckets (they are adjacent, descending in memory) up to min_bucket
+            lo, hi, j = layer[i][0], layer[i][0] + layer[i][1], i
+            while hi - lo < self.min_bucket and j + 1 < len(layer) and layer[j + 1][0] + layer[j + 1][1] == lo:
+                j += 1
+                lo = layer[j][0]
+            if not (off <= lo and hi <= off + ln):
+                raise ValueError("engine bucket outside its segment")
+            msgs += self._cut(model, lo, hi - lo, j)
+            covered.append((lo, hi))
+            i = j + 1
+        covered.sort()
+        cur = off
+        rest = []
+        for lo, hi in covered:
+            if lo > cur:
+                rest += self._cut(model, cur, lo - cur, None)
+            cur = max(cur, hi)
+        if off + ln > cur:
+            rest += self._cut(model, cur, off + ln - cur, None)
+        return msgs + rest
+
+    def buckets(self, seg: int):
+        """(model, offset, length) messages of a segment (compatibility with the round-1 interface)"""
+        return [(m, o, n) for m, o, n, _w in self.plan(seg)]
+
+    def reduce_segment(self, seg: int, flats, layer_events: bool = True):
+        """layer_events=False: the caller modified the gradients on the current stream after the backward (accumulation steps
+        add the running sums there): every message waits for the stream instead of the engine's per-layer events"""
         # KLAB_DDP_FORCE_COLLECTIVE=1: issue the collectives even in a one-rank group (test hook: exercises the comm-stream /
         # RCCL path on a single GPU; the mean over one rank is the identity)
-        if self.world == 1 and not (dist.is_initialized() and os.environ.get("KLAB_DDP_FORCE_COLLECTIVE") == "1"):
+        if not self.world_active():
             return
-        for model, off, n in self.buckets(seg):
+        joined = False  # comm stream already behind the whole segment
+        for model, off, n, wait in self.plan(seg):
             flat = flats.get(model)
             if flat is None or n == 0:
                 continue
             t = flat[off:off + n]
+            self._calls += 1
+            self._bytes += n * t.element_size()
+            self.last_plan.append((seg, model, off, n, wait))
             if t.is_cuda:
                 if self.comm_stream is None:
                     self.comm_stream = torch.cuda.Stream(device=t.device)
-                self.comm_stream.wait_stream(torch.cuda.current_stream(t.device))
+                if (wait is None or joined or not layer_events or self.engine is None
+                        or not self.engine.bucket_wait(seg, wait, self.comm_stream)):
+                    if not joined:
+                        self.comm_stream.wait_stream(torch.cuda.current_stream(t.device))
+                        joined = True
                 with torch.cuda.stream(self.comm_stream):
                     if self._avg_op is not None:
                         dist.all_reduce(t, op=self._avg_op, group=self.pg)
@@ -103,7 +160,7 @@ class DistributedDataParallel(nn.Module):
     native MyModel (`.module`, `forward(*args)`), with segment-overlapped gradient reduction."""
 
     def __init__(self, module, device_ids=None, process_group=None, broadcast_parameters=True, max_bucket_elems=64 << 20,
-                 overlap_optimizer=False):
+                 overlap_optimizer=False, min_bucket_elems=6 << 20):
         """overlap_optimizer=True: backward returns without joining the last all-reduces; `optim.FusedAdam.step()` then
         updates segment 0 (decoder + embedding) while segment 1 (encoder) is still reducing.  Only for loops whose next
         consumer of the gradients is FusedAdam (the reference's loop, ref/train.py:62-69); anything else that reads
@@ -114,7 +171,7 @@ class DistributedDataParallel(nn.Module):
         self.device_ids = device_ids
         eng = module._engine
         nseg = 3 if module.args.image_model_train else 2
-        self.reducer = SegmentReducer(eng.segments[:nseg], process_group, max_bucket_elems)
+        self.reducer = SegmentReducer(eng.segments[:nseg], process_group, max_bucket_elems, engine=eng, min_bucket_elems=min_bucket_elems)
         self._nseg = nseg
         module._direct_grads = True
         module._segment_hook = self._on_segment
@@ -125,9 +182,11 @@ class DistributedDataParallel(nn.Module):
                 for p in module.parameters():
                     dist.broadcast(p.data, src=0, group=process_group)
 
-    def _on_segment(self, seg):
+    def _on_segment(self, seg, fresh=True):
+        if seg == 0:
+            self.reducer.last_plan = []
         flats = {"main": self.module._flat.get("main"), "swin": self.module._flat.get("swin")}
-        self.reducer.reduce_segment(seg, flats)
+        self.reducer.reduce_segment(seg, flats, layer_events=fresh)
         if seg == self._nseg - 1:
             if self.overlap_optimizer and self.reducer.world_active():
                 self.module._pending_reduce = self.reducer  # joined per segment by FusedAdam.step / fully by the next forward

@@ -107,6 +107,9 @@ ENGINE_SIGS = {
                                 C.POINTER(C.c_long)], C.c_int),
     "klab_engine_grad_elems": ([C.c_void_p, C.c_int], C.c_long),
     "klab_engine_segment": ([C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_long), C.POINTER(C.c_long)], C.c_int),
+    "klab_engine_num_buckets": ([C.c_void_p, C.c_int], C.c_int),
+    "klab_engine_bucket": ([C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long)], C.c_int),
+    "klab_engine_bucket_wait": ([C.c_void_p, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "klab_engine_workspace_bytes": ([C.c_void_p, C.c_int, C.c_int, C.c_int], C.c_size_t),
     "klab_engine_bind": ([C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                           C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
@@ -121,7 +124,7 @@ ENGINE_SIGS = {
     "klab_engine_adam_step_segment": ([C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                        C.c_float, C.c_float, C.c_void_p], C.c_int),
     "klab_engine_probe_enable": ([C.c_void_p, C.c_int], C.c_int),
-    "klab_engine_probe_read": ([C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_double)], C.c_int),
+    "klab_engine_probe_read": ([C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_double)], C.c_int),
     "klab_engine_loss_ptr": ([C.c_void_p], C.c_void_p),
     "klab_engine_err_ptr": ([C.c_void_p], C.c_void_p),
     "klab_engine_rng_ptr": ([C.c_void_p], C.c_void_p),
@@ -248,6 +251,14 @@ class Engine:
             mi, off, ln = C.c_int(), C.c_long(), C.c_long()
             L.check(self._lib.klab_engine_segment(self._h, s, C.byref(mi), C.byref(off), C.byref(ln)), "klab_engine_segment")
             self.segments.append((self.MODELS[mi.value], off.value, ln.value))
+        self.buckets = []  # per segment: [(offset, length)] of the layer buckets, in the order backward finishes them
+        for sg in range(3):
+            out = []
+            for i in range(max(0, self._lib.klab_engine_num_buckets(self._h, sg))):
+                off, ln = C.c_long(), C.c_long()
+                L.check(self._lib.klab_engine_bucket(self._h, sg, i, C.byref(off), C.byref(ln)), "klab_engine_bucket")
+                out.append((off.value, ln.value))
+            self.buckets.append(out)
         self._keep = None
         self.shape = None
 
@@ -346,6 +357,15 @@ class Engine:
         L.check(self._lib.klab_engine_adam_step(self._h, m.data_ptr(), v.data_ptr(), lr, beta1, beta2, eps, weight_decay, bias_corr1,
                                                 bias_corr2, L.stream_ptr()), "klab_engine_adam_step")
 
+    def bucket_wait(self, segment, i, stream):
+        """`stream` (torch.cuda.Stream) waits until layer bucket i of the last backward of `segment` is final; False when the
+        engine has no per-layer events for it (graph replay): the caller then waits for the whole segment."""
+        rc = self._lib.klab_engine_bucket_wait(self._h, int(segment), int(i), stream.cuda_stream)
+        if rc == L.ERR_UNSUPPORTED:
+            return False
+        L.check(rc, "klab_engine_bucket_wait")
+        return True
+
     def get_rng(self):
         """(base seed, forwards since seeding) of the device-side dropout RNG; synchronises the current stream"""
         b, n = C.c_uint32(), C.c_uint32()
@@ -362,10 +382,11 @@ class Engine:
     def probe_enable(self, on=True):
         L.check(self._lib.klab_engine_probe_enable(self._h, int(on)), "klab_engine_probe_enable")
 
-    def probe_read(self):
-        """(launches, total_ms, flops_per_launch) of the LM-head GEMM since probe_enable(); call after a synchronize."""
+    def probe_read(self, channel=0):
+        """(launches, total_ms, total_flops) of a probe channel since probe_enable() -- 0: LM-head logits GEMM, 1: grouped
+        weight-gradient launches; call after a synchronize."""
         n, ms, fl = C.c_int(), C.c_float(), C.c_double()
-        L.check(self._lib.klab_engine_probe_read(self._h, C.byref(n), C.byref(ms), C.byref(fl)), "klab_engine_probe_read")
+        L.check(self._lib.klab_engine_probe_read(self._h, int(channel), C.byref(n), C.byref(ms), C.byref(fl)), "klab_engine_probe_read")
         return n.value, ms.value, fl.value
 
     def buffer(self, name):

@@ -161,7 +161,9 @@ class _LossFn(torch.autograd.Function):
                     if model._segment_hook is not None:
                         for s2 in range(nseg):
                             if seg_model[s2] == seg_model[seg]:
-                                model._segment_hook(s2)
+                                # the running sums were added on the current stream AFTER the engine's per-layer events:
+                                # the reducer must order itself behind the stream, not behind those events
+                                model._segment_hook(s2, False)
             return (None,) * (5 + ctx.nparams)
         grads = []
         views = {id(p): v for p, v in targets}

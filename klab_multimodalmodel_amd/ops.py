@@ -137,25 +137,29 @@ def t5_attn_bwd(q, k, v, ctx, lse, dctx, dq, dk_out, dv, *, B, H, Lq, Lk, dk, bi
     L.check(lib.klab_t5_attn_bwd(C.byref(a), L.stream_ptr()), "klab_t5_attn_bwd")
 
 
-def _swin_args(qkv, ctx, bias, logit_scale, lse, B, R, w, shift, H, Cc):
+def _swin_args(qkv, ctx, bias, logit_scale, lse, B, R, w, shift, H, Cc, bias_table=None):
     a = L.SwinAttnArgs()
     a.dtype = L.dtype_code(qkv.dtype)
-    a.qkv, a.ctx, a.bias, a.logit_scale, a.lse = qkv.data_ptr(), ctx.data_ptr(), bias.data_ptr(), logit_scale.data_ptr(), L.ptr(lse)
+    a.qkv, a.ctx, a.bias, a.logit_scale, a.lse = qkv.data_ptr(), ctx.data_ptr(), L.ptr(bias), logit_scale.data_ptr(), L.ptr(lse)
+    a.bias_table = L.ptr(bias_table)
     a.B, a.R, a.w, a.shift, a.H, a.C = B, R, w, shift, H, Cc
     return a
 
 
-def swin_attn_fwd(qkv, ctx, bias, logit_scale, lse=None, *, B, R, w, shift, H, C):
+def swin_attn_fwd(qkv, ctx, bias, logit_scale, lse=None, *, B, R, w, shift, H, C, bias_table=None):
+    """bias [H, n, n] dense, or bias=None + bias_table [(2w-1)^2, H] (large windows: looked up per score)"""
     lib = L.load()
-    a = _swin_args(qkv, ctx, bias, logit_scale, lse, B, R, w, shift, H, C)
+    a = _swin_args(qkv, ctx, bias, logit_scale, lse, B, R, w, shift, H, C, bias_table)
     L.check(lib.klab_swin_attn_fwd(C_byref(a), L.stream_ptr()), "klab_swin_attn_fwd")
 
 
-def swin_attn_bwd(qkv, ctx, bias, logit_scale, lse, dctx, dqkv, dbias=None, dlogit_scale=None, *, B, R, w, shift, H, C, mfma=True):
+def swin_attn_bwd(qkv, ctx, bias, logit_scale, lse, dctx, dqkv, dbias=None, dlogit_scale=None, *, B, R, w, shift, H, C, mfma=True,
+                  bias_table=None, dbias_table=None):
     """mfma=True hands the kernel its scratch (when the shape is inside the matrix-core envelope); False forces the VALU form."""
     import torch
     lib = L.load()
-    a = _swin_args(qkv, ctx, bias, logit_scale, lse, B, R, w, shift, H, C)
+    a = _swin_args(qkv, ctx, bias, logit_scale, lse, B, R, w, shift, H, C, bias_table)
+    a.dbias_table = L.ptr(dbias_table)
     a.dctx, a.dqkv, a.dbias, a.dlogit_scale = dctx.data_ptr(), dqkv.data_ptr(), L.ptr(dbias), L.ptr(dlogit_scale)
     nbytes = lib.klab_swin_attn_bwd_ws_bytes(a.dtype, B, R, w, H, C) if mfma else 0
     if nbytes:
@@ -172,6 +176,19 @@ def swin_cpb_bias(coords, index, w0, b0, w2, table, bias, hidden=None, *, n, hea
     L.check(lib.klab_swin_cpb_bias(coords.data_ptr(), index.data_ptr(), w0.data_ptr(), b0.data_ptr(), w2.data_ptr(),
                                    table.data_ptr(), L.ptr(hidden), bias.data_ptr(), coords.shape[0], n, heads, w0.shape[0],
                                    L.stream_ptr()), "klab_swin_cpb_bias")
+
+
+def swin_cpb_table(coords, w0, b0, w2, table, bias_table, hidden=None, *, heads):
+    lib = L.load()
+    L.check(lib.klab_swin_cpb_table(coords.data_ptr(), w0.data_ptr(), b0.data_ptr(), w2.data_ptr(), table.data_ptr(), L.ptr(hidden),
+                                    bias_table.data_ptr(), coords.shape[0], heads, w0.shape[0], L.stream_ptr()), "klab_swin_cpb_table")
+
+
+def swin_cpb_table_bwd(dbias_table, bias_table, coords, hidden, w2, dtable, dw0, db0, dw2, *, heads):
+    lib = L.load()
+    L.check(lib.klab_swin_cpb_table_bwd(dbias_table.data_ptr(), bias_table.data_ptr(), coords.data_ptr(), hidden.data_ptr(), w2.data_ptr(),
+                                        dtable.data_ptr(), dw0.data_ptr(), db0.data_ptr(), dw2.data_ptr(), coords.shape[0], heads,
+                                        hidden.shape[1], L.stream_ptr()), "klab_swin_cpb_table_bwd")
 
 
 def ce_fwd(logits, labels, inv_n, loss_row, loss, write_grad=True):

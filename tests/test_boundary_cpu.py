@@ -142,10 +142,15 @@ def test_argparse_defaults_equal_the_reference(monkeypatch):
 
 def test_span_mask_matches_recorded_reference_output():
     from klab_multimodalmodel_amd.modules.loader import span_mask
-    for g in json.load(open(os.path.join(GOLD, "spanmask.json"))):
+    """45 (seed, caption) pairs produced by the reference's own RedCapsDatasetLoader.__getitem__
+    (tests/golden/make_spanmask_goldens.py): punctuation splitting, the 15 % + 1 count, sentinel numbering, RNG consumption,
+    one-word / empty / whitespace-heavy captions."""
+    vecs = json.load(open(os.path.join(GOLD, "spanmask.json")))["vectors"]
+    assert len(vecs) >= 20
+    for g in vecs:
         torch.manual_seed(g["seed"])
         src, tgt = span_mask(g["caption"])
-        assert (src, tgt) == (g["src"], g["tgt"])
+        assert (src, tgt) == (g["src"], g["tgt"]), g
 
 
 def test_span_mask_properties():

@@ -357,6 +357,83 @@ def test_swin_window_attention_fwd_bwd(ops, dt, B, R, w, shift, H, C):
         assert rel_l2(dq2.float().cpu(), qr.grad) < t
 
 
+def _table_to_dense(btab, index, H, n):
+    """bias[h, i, j] = btab[index[i, j], h] (HF/swinv2:418-428 after the 16*sigmoid)"""
+    return btab[index.view(-1).long()].view(n, n, H).permute(2, 0, 1).contiguous()
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("B,R,w,shift,H,C", [(1, 12, 12, 0, 2, 64), (1, 24, 12, 6, 2, 64), (1, 24, 24, 0, 1, 32), (2, 48, 24, 12, 1, 32),
+                                             (1, 20, 10, 5, 2, 32)])
+def test_swin_large_window_attention_fwd_bwd(ops, dt, B, R, w, shift, H, C):
+    """windows of more than 64 tokens (BASELINE configs[4]: 384 px / window 24 -> n = 576 and 144; HF/swinv2:389-455, 615-618):
+    tiled kernels, the position bias looked up in the (2w-1)^2 x H table; checked against the dense-bias reference, in both
+    bias forms (table and dense), forward + every gradient incl. d(bias table)."""
+    n, ntab = w * w, (2 * w - 1) ** 2
+    _coords, index = O.swin_coords_table_and_index(w, 0, torch.float32)
+    qkv = rnd(B * R * R, 3 * C, seed=1).to(dt)
+    btab = 16 * torch.sigmoid(rnd(ntab, H, seed=2))
+    ls = torch.log(10 * torch.ones(H)) + 0.3 * rnd(H, seed=3)
+    dctx = rnd(B * R * R, C, seed=4).to(dt)
+    qr = qkv.float().clone().requires_grad_(True)
+    tr, lr = btab.clone().requires_grad_(True), ls.clone().requires_grad_(True)
+    bias_dense = _table_to_dense(tr, index, H, n)
+    ref = _swin_attn_ref(qr, bias_dense, lr, B, R, w, shift, H, C)
+    ref.backward(dctx.float())
+    nW = (R // w) ** 2
+    kw = dict(B=B, R=R, w=w, shift=shift, H=H, C=C)
+    t = tol(dt) * 4
+    for form in ("table", "dense"):
+        ctx = torch.empty(B * R * R, C, device="cuda", dtype=dt)
+        lse = torch.empty(B * nW * H * n, device="cuda")
+        dqkv = torch.empty(B * R * R, 3 * C, device="cuda", dtype=dt)
+        dls = torch.zeros(H, device="cuda")
+        if form == "table":
+            dtab = torch.zeros(ntab, H, device="cuda")
+            ops.swin_attn_fwd(dev(qkv), ctx, None, dev(ls), lse, bias_table=dev(btab), **kw)
+            ops.swin_attn_bwd(dev(qkv), ctx, None, dev(ls), lse, dev(dctx), dqkv, None, dls, bias_table=dev(btab), dbias_table=dtab, **kw)
+            assert rel_l2(dtab.cpu(), tr.grad) < t
+        else:
+            bd = _table_to_dense(btab, index, H, n)
+            dbias = torch.zeros(H, n, n, device="cuda")
+            ops.swin_attn_fwd(dev(qkv), ctx, dev(bd), dev(ls), lse, **kw)
+            ops.swin_attn_bwd(dev(qkv), ctx, dev(bd), dev(ls), lse, dev(dctx), dqkv, dbias, dls, **kw)
+            got = torch.zeros(ntab, H).index_add_(0, index.view(-1).long(), dbias.cpu().permute(1, 2, 0).reshape(n * n, H))
+            assert rel_l2(got, tr.grad) < t
+        assert rel_l2(ctx.float().cpu(), ref.detach()) < tol(dt), form
+        assert rel_l2(dqkv.float().cpu(), qr.grad) < t, form
+        assert rel_l2(dls.cpu(), lr.grad) < t * 10, form
+
+
+@pytest.mark.parametrize("w,pw,H", [(12, 6, 4), (24, 12, 2), (8, 0, 3)])
+def test_swin_cpb_table_fwd_bwd(ops, w, pw, H):
+    """table form of the continuous position bias (any window size; HF/swinv2:376-378,418-428,457-492): 16*sigmoid(MLP(coords))
+    and the MLP weight gradients from d(bias table), against autograd through the oracle's dense bias."""
+    sd = {"continuous_position_bias_mlp.0.weight": rnd(512, 2, seed=1).requires_grad_(True),
+          "continuous_position_bias_mlp.0.bias": rnd(512, seed=2).requires_grad_(True),
+          "continuous_position_bias_mlp.2.weight": rnd(H, 512, seed=3, scale=0.1).requires_grad_(True)}
+    n, ntab = w * w, (2 * w - 1) ** 2
+    ref = O.swin_cpb_bias(sd, "", w, pw, H, torch.float32)  # dense [H, n, n]
+    G = rnd(H, n, n, seed=4)
+    (ref * G).sum().backward()
+    coords, index = O.swin_coords_table_and_index(w, pw, torch.float32)
+    coords = coords.view(-1, 2).contiguous()
+    w0, b0, w2 = (sd[k].detach() for k in ("continuous_position_bias_mlp.0.weight", "continuous_position_bias_mlp.0.bias",
+                                           "continuous_position_bias_mlp.2.weight"))
+    table = torch.empty(ntab, H, device="cuda")
+    btab = torch.empty(ntab, H, device="cuda")
+    hidden = torch.empty(ntab, 512, device="cuda")
+    ops.swin_cpb_table(dev(coords), dev(w0), dev(b0), dev(w2), table, btab, hidden, heads=H)
+    assert rel_l2(_table_to_dense(btab.cpu(), index, H, n), ref.detach()) < 1e-5
+    dbtab = torch.zeros(ntab, H).index_add_(0, index.view(-1).long(), G.permute(1, 2, 0).reshape(n * n, H))
+    dtable = torch.empty(ntab, H, device="cuda")
+    dw0, db0, dw2 = torch.zeros(512, 2, device="cuda"), torch.zeros(512, device="cuda"), torch.zeros(H, 512, device="cuda")
+    ops.swin_cpb_table_bwd(dev(dbtab), btab, dev(coords), hidden, dev(w2), dtable, dw0, db0, dw2, heads=H)
+    assert rel_l2(dw2.cpu(), sd["continuous_position_bias_mlp.2.weight"].grad) < 2e-5
+    assert rel_l2(dw0.cpu(), sd["continuous_position_bias_mlp.0.weight"].grad) < 2e-5
+    assert rel_l2(db0.cpu(), sd["continuous_position_bias_mlp.0.bias"].grad) < 2e-5
+
+
 @pytest.mark.parametrize("w,H", [(4, 2), (7, 4), (2, 8)])
 def test_swin_cpb_bias(ops, w, H):
     sd = {"continuous_position_bias_mlp.0.weight": rnd(512, 2, seed=1), "continuous_position_bias_mlp.0.bias": rnd(512, seed=2),
