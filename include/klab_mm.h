@@ -29,6 +29,7 @@ extern "C" {
 
 #define KLAB_F32 0
 #define KLAB_BF16 1
+#define KLAB_FP8 2 /* engine mode only (klab_model_cfg.dtype): bf16 storage and backward, forward Linear GEMMs on fp8 MFMA */
 
 #define KLAB_ACT_NONE 0
 #define KLAB_ACT_RELU 1 /* T5 DenseReluDense, HF/t5:83-94 */
@@ -64,6 +65,18 @@ typedef struct klab_gemm_args {
                     float atomics (summation order, hence the last bits, then vary run to run) */
 } klab_gemm_args;
 int klab_gemm(const klab_gemm_args* args, void* stream);
+/* fp8 forward GEMM (BASELINE configs[4]): C = epilogue(alpha * sa[m] * sb[n * b_scale_stride] * sum_k A8(m,k) B8(n,k)).
+ * A, B: OCP e4m3 bytes, both K-major (lda / ldb in bytes = elements); a_row_scale [M] and b_row_scale are the per-row
+ * dequantisation scales klab_quant_fp8_rows / klab_quant_fp8_arena produce (amax / 448).  Every other field of klab_gemm_args
+ * as for klab_gemm with dtype = KLAB_BF16 (bias, act, dropout, residual, bf16 / f32 output); accumulate is not supported.
+ * K % 16 == 0, 16-byte aligned operands.                                                                             */
+int klab_gemm_fp8(const klab_gemm_args* a, const float* a_row_scale, const float* b_row_scale, long b_scale_stride, void* stream);
+/* x [M, K] bf16 rows -> x8 [M, K] e4m3 + row_scale[m] = amax(row) / 448 (1 for an all-zero row); K <= 4096, K % 8 == 0 */
+int klab_quant_fp8_rows(const void* x, long ldx, int M, int K, void* x8, long ld8, float* row_scale, void* stream);
+/* all GEMM weights of a bf16 arena in one launch: desc_dev[i] = {long arena_off, rows, K, first_row}; row r of tensor i is
+ * quantised to arena_fp8 + off + r*K with its scale at scales[(off + r*K) / 8]                                         */
+int klab_quant_fp8_arena(const void* desc_dev, int ndesc, long total_rows, const void* arena_bf16, void* arena_fp8, float* scales,
+                         void* stream);
 /* n independent GEMMs.  Split-K weight-gradient members (bf16, both operands m-major, f32 C with accumulate + atomic_ok, no
  * epilogue extras) are batched into single launches of up to 8; every other member is run through klab_gemm. */
 int klab_gemm_grouped(const klab_gemm_args* list, int n, void* stream);
@@ -261,7 +274,7 @@ typedef struct klab_t5_cfg {    /* HF/t5cfg:44-62,82-83 */
 typedef struct klab_model_cfg {
   klab_swin_cfg swin;
   klab_t5_cfg lang, main;
-  int dtype;      /* KLAB_F32 parity mode | KLAB_BF16 */
+  int dtype;      /* KLAB_F32 parity mode | KLAB_BF16 | KLAB_FP8 (bf16 + fp8 forward GEMMs with per-row scales) */
   int train_swin; /* args.image_model_train (ref/models/model.py:15) */
 } klab_model_cfg;
 typedef struct klab_engine klab_engine;
@@ -322,6 +335,14 @@ int klab_engine_adam_step_segment(klab_engine* e, int segment, float* m, float* 
 int klab_adam_step_range(const void* desc_dev, int ndesc, long begin4, long end4, const float* grads, float* m, float* v, void* arena,
                          int dtype, float lr, float beta1, float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,
                          void* stream);
+/* Greedy decoding with a K/V cache (ref/models/model.py:27-28, HF/t5:308-332): the decoder over ONE new position t >= 1 per
+ * sample.  Precondition: a klab_engine_forward in evaluation mode on this binding (prefill: encoder, cross K/V, position 0),
+ * then steps 1, 2, ... in order; the per-layer q|k|v buffers of the binding are the cache.  prev_tokens [B] (device) = ids
+ * generated at position t-1.  Logits of position t: klab_engine_buffer("logits_step") [B, vocab].                        */
+int klab_engine_decode_step(klab_engine* e, int t, const long long* prev_tokens, void* stream);
+/* one query row per (batch, head) against cached keys / values (element strides; bias_row [H, bias_ld] or NULL) */
+int klab_t5_decode_attn(int dtype, const void* q, long q_bstride, const void* k, const void* v, long kv_bstride, long ldk,
+                        const float* bias_row, long bias_ld, void* ctx, long ctx_bstride, int B, int H, int Lk, int dk, void* stream);
 /* segment 0: LM head + decoder + tied embedding; 1: encoder; 2: Swin (no-op unless train_swin).
  * dloss_dev: device scalar d(objective)/d(loss) (NULL = 1).                                       */
 int klab_engine_backward(klab_engine* e, int segment, const float* dloss_dev, void* stream);

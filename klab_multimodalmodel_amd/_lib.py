@@ -8,7 +8,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KLAB_LIB", os.path.join(HERE, "libklab_mm.so"))  # KLAB_LIB: A/B-test another build
 
-F32, BF16 = 0, 1
+F32, BF16, FP8 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 AUX_NONE, AUX_NONZERO, AUX_DGELU = 0, 1, 2
 ERR_UNSUPPORTED, ERR_BADARG = -2, -3
@@ -59,9 +59,13 @@ SIGNATURES = {
     "klab_layernorm_bwd": [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, u32, vp],
     "klab_t5_attn_fwd": [C.POINTER(AttnArgs), vp],
     "klab_t5_attn_bwd": [C.POINTER(AttnArgs), vp],
+    "klab_t5_decode_attn": [i32, vp, i64, vp, vp, i64, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp],
     "klab_dbias_reduce": [vp, i32, vp, i32, i32, i32, i32, vp],
     "klab_swin_mlp_fused": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
     "klab_gemm_grouped": [vp, i32, vp],
+    "klab_gemm_fp8": [C.POINTER(GemmArgs), vp, vp, i64, vp],
+    "klab_quant_fp8_rows": [vp, i64, i32, i32, vp, i64, vp, vp],
+    "klab_quant_fp8_arena": [vp, i32, i64, vp, vp, vp, vp],
     "klab_swin_qkv_attn_fused": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "klab_swin_proj_ln_fused": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
     "klab_swin_attn_fwd": [C.POINTER(SwinAttnArgs), vp],
@@ -138,6 +142,8 @@ def dtype_code(torch_dtype):
         return F32
     if torch_dtype == torch.bfloat16:
         return BF16
+    if torch_dtype == "fp8":
+        return FP8
     raise ValueError(f"unsupported dtype {torch_dtype}")
 
 

@@ -332,3 +332,79 @@ extern "C" int klab_dbias_reduce(const void* ds_ws, int dtype, float* dbias, int
   if (!ds_ws || !dbias || dtype != KLAB_BF16) return KLAB_ERR_BADARG;
   return dbias_reduce_dispatch(ds_ws, dbias, nbatch, H, Lq, Lk, (hipStream_t)stream);
 }
+
+// ---- one-position decode attention with a K/V cache (greedy generation, ref/models/model.py:27-28; HF/t5:308-332) -----------
+// One wave per (batch element, head): the single query row of position t against keys 0..Lk-1 held in the cache.
+//   q  : row of sample b at q + b*q_bstride;   K/V: rows j of sample b at k + (b*kv_bstride + j*ldk)   (element strides)
+//   bias_row: [H, bias_ld] values for THIS query position (relative-position bias row t), NULL for cross-attention
+// Lanes split the keys (online softmax per lane, merged by a wave reduction); head dim 16 / 32 / 64 / 128, T = f32 | bf16.
+namespace klab {
+template <typename T, int DK>
+__global__ __launch_bounds__(64) void decode_attn_kernel(const T* __restrict__ q, long q_bstride, const T* __restrict__ k, const T* __restrict__ v,
+                                                         long kv_bstride, long ldk, const float* __restrict__ bias_row, long bias_ld,
+                                                         T* __restrict__ ctx, long ctx_bstride, int H, int Lk) {
+  const int b = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
+  const T* qr = q + (long)b * q_bstride + h * DK;
+  float qv[DK], o[DK];
+#pragma unroll
+  for (int c = 0; c < DK; ++c) { qv[c] = to_f32(qr[c]); o[c] = 0.f; }
+  float m = -INFINITY, l = 0.f;
+  for (int j = lane; j < Lk; j += 64) {
+    const T* kr = k + (long)b * kv_bstride + (long)j * ldk + h * DK;
+    const T* vr = v + (long)b * kv_bstride + (long)j * ldk + h * DK;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < DK; ++c) s += qv[c] * to_f32(kr[c]);  // unscaled scores (HF/t5:196-197)
+    if (bias_row) s += bias_row[(long)h * bias_ld + j];
+    const float mn = fmaxf(m, s), corr = __expf(m - mn), pe = __expf(s - mn);
+    l = l * corr + pe;
+#pragma unroll
+    for (int c = 0; c < DK; ++c) o[c] = o[c] * corr + pe * to_f32(vr[c]);
+    m = mn;
+  }
+  float mw = m;
+#pragma unroll
+  for (int s2 = 32; s2 > 0; s2 >>= 1) mw = fmaxf(mw, __shfl_xor(mw, s2, 64));
+  const float f = (m == -INFINITY) ? 0.f : __expf(m - mw);
+  float lw = l * f;
+#pragma unroll
+  for (int s2 = 32; s2 > 0; s2 >>= 1) lw += __shfl_xor(lw, s2, 64);
+  const float il = 1.f / lw;
+  T* orow = ctx + (long)b * ctx_bstride + h * DK;
+#pragma unroll
+  for (int c = 0; c < DK; ++c) {
+    float x = o[c] * f;
+#pragma unroll
+    for (int s2 = 32; s2 > 0; s2 >>= 1) x += __shfl_xor(x, s2, 64);
+    if (lane == 0) orow[c] = from_f32<T>(x * il);
+  }
+}
+template <typename T>
+static int launch_decode_attn(const void* q, long q_bstride, const void* k, const void* v, long kv_bstride, long ldk, const float* bias_row,
+                              long bias_ld, void* ctx, long ctx_bstride, int B, int H, int Lk, int dk, hipStream_t s) {
+#define DEC_LAUNCH(D)                                                                                                              \
+  hipLaunchKernelGGL((decode_attn_kernel<T, D>), dim3(B * H), dim3(64), 0, s, (const T*)q, q_bstride, (const T*)k, (const T*)v, kv_bstride, \
+                     ldk, bias_row, bias_ld, (T*)ctx, ctx_bstride, H, Lk)
+  switch (dk) {
+    case 16: DEC_LAUNCH(16); break;
+    case 32: DEC_LAUNCH(32); break;
+    case 64: DEC_LAUNCH(64); break;
+    case 128: DEC_LAUNCH(128); break;
+    default: return KLAB_ERR_UNSUPPORTED;
+  }
+#undef DEC_LAUNCH
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+}  // namespace klab
+
+extern "C" int klab_t5_decode_attn(int dtype, const void* q, long q_bstride, const void* k, const void* v, long kv_bstride, long ldk,
+                                   const float* bias_row, long bias_ld, void* ctx, long ctx_bstride, int B, int H, int Lk, int dk,
+                                   void* stream) {
+  using namespace klab;
+  if (!q || !k || !v || !ctx || B <= 0 || H <= 0 || Lk <= 0) return KLAB_ERR_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == KLAB_BF16) return launch_decode_attn<bf16_t>(q, q_bstride, k, v, kv_bstride, ldk, bias_row, bias_ld, ctx, ctx_bstride, B, H, Lk, dk, s);
+  if (dtype == KLAB_F32) return launch_decode_attn<float>(q, q_bstride, k, v, kv_bstride, ldk, bias_row, bias_ld, ctx, ctx_bstride, B, H, Lk, dk, s);
+  return KLAB_ERR_BADARG;
+}

@@ -106,6 +106,12 @@ struct klab_engine {
   std::vector<const float*> W[3];
   float* G[3] = {nullptr, nullptr, nullptr};
   void* warena = nullptr; float* farena = nullptr;
+  // fp8 mode (BASELINE configs[4]): e4m3 copies of the GEMM weights + per-row scales, refreshed from the bf16 arena at the
+  // start of every forward; activations are quantised per token in front of each forward Linear GEMM.  Backward stays bf16.
+  bool fp8 = false;
+  void* w8 = nullptr; float* wscale = nullptr; void* qdesc = nullptr; int n_qdesc = 0; long q_rows = 0;
+  void* x8 = nullptr; float* xscale = nullptr; long x8_bytes = 0, xscale_rows = 0;
+  void* x8s = nullptr; float* xscales = nullptr; long x8s_bytes = 0, xscales_rows = 0;  // the side stream's own staging (language encoder)
   void* cast_desc = nullptr; int n_cast = 0; long cast_total4 = 0;      // trainable GEMM weights (cast every forward)
   void* adam_desc = nullptr; int n_adam = 0; long adam_total4 = 0, adam_split4 = 0;
   // RMS-norm weight gradients of a stack: per-workgroup partials of every norm, folded by one reduction per stack
@@ -117,6 +123,9 @@ struct klab_engine {
   const int *enc_bucket = nullptr, *dec_bucket = nullptr, *lang_bucket = nullptr;
   std::vector<const float*> swin_coords; std::vector<const int*> swin_index; std::vector<int> swin_ntab;
   T5StackBufs lang, enc, dec;
+  // greedy decoding with a K/V cache (klab_engine_decode_step): one position per sample, contiguous [B, .] rows
+  float* dc_h[2] = {nullptr, nullptr}; float* dc_rstd = nullptr;
+  void *dc_xn = nullptr, *dc_q = nullptr, *dc_ctx = nullptr, *dc_hmid = nullptr, *dc_out = nullptr, *dc_logits = nullptr;
   // lang scratch (no grad => reused across layers)
   void* kv_all = nullptr; void* dkv_all = nullptr;
   void* logits = nullptr; float *loss_row = nullptr, *inv_n = nullptr, *loss = nullptr;
@@ -260,7 +269,8 @@ inline long pad8(long n) { return (n + 7) & ~7L; }
 // weight-arena (compute dtype) offsets; q|k|v and the decoder's cross k|v of ALL layers are adjacent
 void plan_arenas(klab_engine* e) {
   long w = 0, f = 0;
-  auto putw = [&](std::vector<ParamInfo>& v, int i) { if (i >= 0) { v[i].warena_off = w; w += pad8(v[i].numel); } };
+  // (16-element alignment: the fp8 copy of the arena uses the same element offsets as byte offsets)
+  auto putw = [&](std::vector<ParamInfo>& v, int i) { if (i >= 0) { v[i].warena_off = w; w += (v[i].numel + 15) & ~15L; } };
   auto t5 = [&](std::vector<ParamInfo>& v, T5Idx& ix, bool is_main) {
     putw(v, ix.shared);  // tied LM head operand (and nothing else: embeddings are gathered from the f32 master)
     for (auto& l : ix.dec) { putw(v, l.q); putw(v, l.k); putw(v, l.v); putw(v, l.o); putw(v, l.cq); putw(v, l.co); putw(v, l.wi); putw(v, l.wo); }
@@ -283,7 +293,7 @@ void plan_arenas(klab_engine* e) {
       e->pe_k0 = sc.in_ch * sc.patch * sc.patch;
       e->pe_kp = (e->cfg.dtype == KLAB_BF16 && sc.patch == 4) ? ((e->pe_k0 + 31) & ~31) : e->pe_k0;
       v[e->si.pew].warena_off = w;
-      w += pad8((long)sc.embed_dim * e->pe_kp);
+      w += ((long)sc.embed_dim * e->pe_kp + 15) & ~15L;
     }
     for (auto& st : e->si.st) {
       for (auto& k : st.blk) {
@@ -430,6 +440,26 @@ size_t plan_workspace(klab_engine* e, void* base, int B, int Ls, int Lt) {
   e->tgt_buf = (long long*)b.take((size_t)B * Lt * 8);
   e->warena = b.take((size_t)e->warena_elems * es);
   e->farena = (float*)b.take((size_t)e->farena_elems * 4);
+  if (e->fp8) {
+    e->w8 = b.take((size_t)e->warena_elems);
+    e->wscale = (float*)b.take((size_t)(e->warena_elems / 8 + 1) * 4);
+    e->qdesc = b.take(sizeof(long) * 4 * (e->P[0].size() + e->P[1].size() + e->P[2].size() + 1));
+    // activation staging: the widest A operand of any forward Linear (rows x K bytes) and its row scales
+    const long R0q = c.swin.image_size / c.swin.patch;
+    long mk = (long)B * (Le > Lt ? Le : Lt) * (c.main.d_ff > c.main.d_model ? c.main.d_ff : c.main.d_model);
+    long rows = (long)B * (Le > Lt ? Le : Lt);
+    for (int st = 0; st < c.swin.n_stages; ++st) {
+      const long M = (long)B * (R0q >> st) * (R0q >> st), C = (long)c.swin.embed_dim << st;
+      if (M * C * c.swin.mlp_ratio > mk) mk = M * C * c.swin.mlp_ratio;
+      if (M > rows) rows = M;
+    }
+    e->x8_bytes = mk; e->xscale_rows = rows;
+    e->x8 = b.take((size_t)mk);
+    e->xscale = (float*)b.take((size_t)rows * 4);
+    e->x8s_bytes = (long)B * Ls * (c.lang.d_ff > c.lang.d_model ? c.lang.d_ff : c.lang.d_model); e->xscales_rows = (long)B * Ls;
+    e->x8s = b.take((size_t)e->x8s_bytes);
+    e->xscales = (float*)b.take((size_t)e->xscales_rows * 4);
+  }
   // two descriptor groups (trainable / frozen); the patch-embedding weight contributes one descriptor per row
   e->cast_desc = b.take(sizeof(long) * 3 * 2 * (e->P[0].size() + e->P[1].size() + e->P[2].size() + c.swin.embed_dim + 1));
   e->fcast_desc = b.take(sizeof(long) * 3 * (e->P[0].size() + 1));
@@ -450,6 +480,11 @@ size_t plan_workspace(klab_engine* e, void* base, int B, int Ls, int Lt) {
   e->kv_all = b.take((size_t)Me * nld * 2 * inner * es);
   e->dkv_all = b.take((size_t)Me * nld * 2 * inner * es);
   e->logits = b.take((size_t)Md * c.main.vocab * es);
+  e->dc_h[0] = (float*)b.take((size_t)B * d * 4); e->dc_h[1] = (float*)b.take((size_t)B * d * 4);
+  e->dc_rstd = (float*)b.take((size_t)B * 4);
+  e->dc_xn = b.take((size_t)B * d * es); e->dc_q = b.take((size_t)B * inner * es); e->dc_ctx = b.take((size_t)B * inner * es);
+  e->dc_hmid = b.take((size_t)B * ff * es); e->dc_out = b.take((size_t)B * d * es);
+  e->dc_logits = b.take((size_t)B * c.main.vocab * es);
   e->loss_row = (float*)b.take((size_t)Md * 4);
   const long Mx = Me > Md ? Me : Md;
   e->dh_a = (float*)b.take((size_t)Mx * d * 4);
@@ -570,12 +605,32 @@ klab_gemm_args G0(const Ctx& c, int M, int N, int K, const void* A, long lda, in
 inline void* woff(const Ctx& c, long off) { return (char*)c.e->warena + (size_t)off * c.es; }
 inline void* eoff(const Ctx& c, void* p, long elems) { return (char*)p + (size_t)elems * c.es; }
 
+inline bool fp8_weight_ok(long K) { return (K & 15) == 0 && K >= 16 && K <= 4096; }
+// A forward Linear product x[M,K] @ W[N,K]^T (+ epilogue).  fp8 mode: x is quantised per token into the stream's staging
+// buffer and the product runs on the fp8 matrix cores against the e4m3 copy of W (arena offset woffv); otherwise klab_gemm.
+int fwd_gemm(const Ctx& c, klab_gemm_args& g, long woffv) {
+  klab_engine* e = c.e;
+  if (e->fp8 && woffv >= 0 && !(woffv & 15) && g.a_kmajor && g.b_kmajor && !g.accumulate && fp8_weight_ok(g.K) && g.lda == g.K && g.ldb == g.K) {
+    const bool side = c.s == e->side;
+    void* x8 = side ? e->x8s : e->x8;
+    float* xs = side ? e->xscales : e->xscale;
+    const long cap = side ? e->x8s_bytes : e->x8_bytes, rows = side ? e->xscales_rows : e->xscale_rows;
+    if ((long)g.M * g.K <= cap && g.M <= rows) {
+      RC(klab_quant_fp8_rows(g.A, g.lda, g.M, g.K, x8, g.K, xs, c.ws()));
+      klab_gemm_args q = g;
+      q.A = x8; q.B = (const char*)e->w8 + woffv;
+      return klab_gemm_fp8(&q, xs, e->wscale + woffv / 8, g.K / 8, c.ws());
+    }
+  }
+  return klab_gemm(&g, c.ws());
+}
+
 // y = x @ W^T   (W [N,K] from the weight arena)
 int linear_fwd(const Ctx& c, const void* x, int M, int K, long woffv, int N, void* y, long ldy, int ydt, const float* bias = nullptr,
                int act = 0) {
   klab_gemm_args g = G0(c, M, N, K, x, K, 1, woff(c, woffv), K, 1, y, ldy, ydt);
   g.bias = bias; g.act = act;
-  return klab_gemm(&g, c.ws());
+  return fwd_gemm(c, g, woffv);
 }
 // dX[M,K] = dY[M,N] @ W[N,K]
 int linear_dgrad(const Ctx& c, const void* dy, long lddy, int M, int N, long woffv, int K, void* dx, int dxdt) {
@@ -593,7 +648,7 @@ int t5_sublayer_out(const Ctx& c, const void* x, int M, int K, long woffv, int d
   klab_gemm_args g = G0(c, M, d, K, x, K, 1, woff(c, woffv), K, 1, hout, d, KLAB_F32);
   g.residual = resid; g.ldr = d; g.r_dtype = KLAB_F32;
   g.drop_p = p; g.seed_dev = c.e->seed_dev; g.drop_tag = tag;
-  return klab_gemm(&g, c.ws());
+  return fwd_gemm(c, g, woffv);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -644,7 +699,7 @@ int t5_stack_forward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Par
     {
       klab_gemm_args g = G0(c, M, ff, d, b.xn3, d, 1, woff(c, P[l.wi].warena_off), d, 1, b.hmid, ff, c.dt);
       g.act = KLAB_ACT_RELU; g.drop_p = p; g.seed_dev = c.e->seed_dev; g.drop_tag = tag_of(stack_id, (int)i, SITE_MID);
-      RC(klab_gemm(&g, c.ws()));
+      RC(fwd_gemm(c, g, P[l.wi].warena_off));
     }
     RC(t5_sublayer_out(c, b.hmid, M, ff, P[l.wo].warena_off, d, s.h[j], s.h[j + 1], p, tag_of(stack_id, (int)i, SITE_FFN_OUT)));
     ++j;
@@ -947,7 +1002,7 @@ int swin_backward(const Ctx& c, const float* dh0, float p_in);
 // ================================================================================================
 extern "C" klab_engine* klab_engine_create(const klab_model_cfg* cfg) {
   if (!cfg) return nullptr;
-  if (cfg->dtype != KLAB_F32 && cfg->dtype != KLAB_BF16) return nullptr;
+  if (cfg->dtype != KLAB_F32 && cfg->dtype != KLAB_BF16 && cfg->dtype != KLAB_FP8) return nullptr;
   const klab_swin_cfg& s = cfg->swin;
   if (s.n_stages < 1 || s.n_stages > 8 || s.patch <= 0 || s.image_size % s.patch) return nullptr;
   const long Cl = (long)s.embed_dim << (s.n_stages - 1);
@@ -955,6 +1010,7 @@ extern "C" klab_engine* klab_engine_create(const klab_model_cfg* cfg) {
   if (Cl != cfg->main.d_model || cfg->lang.d_model != cfg->main.d_model) return nullptr;
   klab_engine* e = new klab_engine();
   e->cfg = *cfg;
+  if (cfg->dtype == KLAB_FP8) { e->fp8 = true; e->cfg.dtype = KLAB_BF16; }  // storage, backward and every non-GEMM kernel: bf16
   build_swin_params(cfg->swin, e->P[0], e->si);
   build_t5_params(cfg->lang, true, e->P[1], e->li);
   build_t5_params(cfg->main, false, e->P[2], e->mi);
@@ -1040,7 +1096,7 @@ extern "C" size_t klab_engine_workspace_bytes(klab_engine* e, int B, int Ls, int
   klab_engine tmp;
   tmp.cfg = e->cfg;
   for (int m = 0; m < 3; ++m) tmp.P[m].resize(e->P[m].size());
-  tmp.warena_elems = e->warena_elems; tmp.farena_elems = e->farena_elems;
+  tmp.warena_elems = e->warena_elems; tmp.farena_elems = e->farena_elems; tmp.fp8 = e->fp8;
   return plan_workspace(&tmp, nullptr, B, Ls, Lt);
 }
 
@@ -1129,6 +1185,26 @@ extern "C" int klab_engine_bind(klab_engine* e, int B, int Ls, int Lt, void* wor
     RC((int)hipMemsetAsync(e->farena, 0, (size_t)e->farena_elems * 4, hs));
     if (n) {
       hipError_t er = hipMemcpyAsync(e->fcast_desc, d.data(), d.size() * sizeof(long), hipMemcpyHostToDevice, hs);
+      if (er != hipSuccess) return (int)er;
+      er = hipStreamSynchronize(hs);
+      if (er != hipSuccess) return (int)er;
+    }
+  }
+  if (e->fp8) {  // fp8 weight table: every arena tensor as rows x K (the padded patch-embedding weight stays bf16)
+    std::vector<long> d;
+    long row0 = 0; int n = 0;
+    for (int m = 0; m < 3; ++m)
+      for (size_t i = 0; i < e->P[m].size(); ++i) {
+        const ParamInfo& p = e->P[m][i];
+        if (p.warena_off < 0 || p.shape.empty() || (m == 0 && (int)i == e->si.pew)) continue;
+        const long rows = p.shape[0], K = p.numel / rows;
+        if (!fp8_weight_ok(K) || (p.warena_off & 15)) continue;
+        d.push_back(p.warena_off); d.push_back(rows); d.push_back(K); d.push_back(row0);
+        row0 += rows; ++n;
+      }
+    e->n_qdesc = n; e->q_rows = row0;
+    if (n) {
+      hipError_t er = hipMemcpyAsync(e->qdesc, d.data(), d.size() * sizeof(long), hipMemcpyHostToDevice, hs);
       if (er != hipSuccess) return (int)er;
       er = hipStreamSynchronize(hs);
       if (er != hipSuccess) return (int)er;
@@ -1263,6 +1339,9 @@ int forward_part_a(klab_engine* e, hipStream_t stream, float p, bool refresh_fro
       RC(klab_cast_pack(e->cast_desc_frozen, e->n_cast_frozen, e->cast_total4_frozen, e->warena, c.dt, c.ws()));
     if (e->n_fcast) RC(klab_cast_pack(e->fcast_desc, e->n_fcast, e->fcast_total4, e->farena, KLAB_F32, c.ws()));
   }
+  // fp8 mode: e4m3 copies + per-row scales of every GEMM weight, from the bf16 arena (which the casts above or the fused
+  // optimizer step just refreshed)
+  if (e->fp8 && e->n_qdesc) RC(klab_quant_fp8_arena(e->qdesc, e->n_qdesc, e->q_rows, e->warena, e->w8, e->wscale, c.ws()));
   const int B = e->B, d = cfg.main.d_model;
   // 2./3. The two towers are independent until the concat.  Swin-V2 (ref/models/model.py:22, rows [0, N_img)) is
   //    enqueued FIRST on the main stream -- its launches are long, so the host runs far ahead -- and the frozen
@@ -1392,7 +1471,7 @@ extern "C" int klab_engine_forward(klab_engine* e, const float* pixels, const lo
     klab_engine::Probe& pr = e->probe[0];
     const bool probe = e->probe_on && pr.n < (int)pr.a.size();
     if (probe) RC((int)hipEventRecord(pr.a[pr.n], c.s));
-    RC(klab_gemm(&g, c.ws()));
+    RC(fwd_gemm(c, g, e->P[2][e->mi.shared].warena_off));
     if (probe) { RC((int)hipEventRecord(pr.b[pr.n], c.s)); pr.flops[pr.n++] = 2.0 * Md * (double)V * d; }
     RC(run_graphed(e, want_grad ? 3 : 2, c.s, [&]() {
       return klab_ce_fwd(e->logits, V, c.dt, e->tgt_buf, Md, V, e->inv_n, e->loss_row, e->loss, want_grad, c.ws());
@@ -1445,7 +1524,70 @@ extern "C" const void* klab_engine_buffer(const klab_engine* e, const char* name
   if (!strcmp(name, "encoder_out")) { set((long)e->B * e->Le, d, e->cfg.dtype); return e->enc.out_t; }
   if (!strcmp(name, "decoder_out")) { set((long)e->B * e->Lt, d, e->cfg.dtype); return e->dec.out_t; }
   if (!strcmp(name, "logits")) { set((long)e->B * e->Lt, e->cfg.main.vocab, e->cfg.dtype); return e->logits; }
+  if (!strcmp(name, "logits_step")) { set((long)e->B, e->cfg.main.vocab, e->cfg.dtype); return e->dc_logits; }
   return nullptr;
+}
+
+// Greedy decoding with a K/V cache (ref/models/model.py:27-28 -> generate; HF/t5:308-332): the decoder over ONE new position
+// t >= 1 per sample.  Precondition: a klab_engine_forward in evaluation mode on this binding (the prefill: encoder output,
+// cross-attention K/V of all layers, the decoder's position-bias table, and -- position 0 being the start token whatever the
+// target holds -- the self-attention K/V rows of position 0), then decode steps 1, 2, ... in order.  The per-layer q|k|v
+// buffer [B*Lt, 3*inner] of the training path IS the cache: the new position's fused projection is written into row
+// b*Lt + t, attention reads rows b*Lt + 0..t.  prev_tokens [B] = the ids generated at position t-1 (the decoder input at t,
+// HF/t5:618-637).  Result: logits of position t in the "logits_step" buffer [B, vocab].
+extern "C" int klab_engine_decode_step(klab_engine* e, int t, const long long* prev_tokens, void* stream) {
+  if (!e || !e->bound || !prev_tokens || t < 1 || t >= e->Lt) return KLAB_ERR_BADARG;
+  Ctx c{e, (hipStream_t)stream, e->cfg.dtype, e->es};
+  const klab_t5_cfg& cfg = e->cfg.main;
+  const auto& P = e->P[2];
+  const auto& W = e->W[2];
+  const int B = e->B, Lt = e->Lt, Le = e->Le, d = cfg.d_model, H = cfg.n_heads, dk = cfg.d_kv, inner = H * dk, ff = cfg.d_ff;
+  const int nld = cfg.n_dec_layers;
+  const long kv_ld = (long)nld * 2 * inner;
+  RC(klab_embed_fwd(prev_tokens, 0, 1, cfg.start_id, cfg.pad_id, W[e->mi.shared], cfg.vocab, e->dc_h[0], B, d, 0.f, nullptr, 0, e->err_dev,
+                    c.ws()));
+  float* h = e->dc_h[0];
+  float* h2 = e->dc_h[1];
+  auto proj_res = [&](const void* x, int K, long woffv) -> int {  // h2 = h + x @ W^T  (f32 residual stream)
+    klab_gemm_args g = G0(c, B, d, K, x, K, 1, woff(c, woffv), K, 1, h2, d, KLAB_F32);
+    g.residual = h; g.ldr = d; g.r_dtype = KLAB_F32;
+    RC(fwd_gemm(c, g, woffv));
+    float* tmp = h; h = h2; h2 = tmp;
+    return 0;
+  };
+  for (int i = 0; i < nld; ++i) {
+    const T5LayerIdx& l = e->mi.dec[i];
+    T5LayerBufs& b = e->dec.L[i];
+    // self attention over the cache
+    RC(klab_rmsnorm_fwd(h, W[l.ln0], e->dc_xn, c.dt, nullptr, e->dc_rstd, B, d, cfg.ln_eps, 0, 0, 0, 0.f, nullptr, 0, c.ws()));
+    {
+      klab_gemm_args g = G0(c, B, 3 * inner, d, e->dc_xn, d, 1, woff(c, P[l.q].warena_off), d, 1, eoff(c, b.qkv, (long)t * 3 * inner),
+                            (long)Lt * 3 * inner, c.dt);
+      RC(fwd_gemm(c, g, P[l.q].warena_off));
+    }
+    RC(klab_t5_decode_attn(c.dt, eoff(c, b.qkv, (long)t * 3 * inner), (long)Lt * 3 * inner, eoff(c, b.qkv, inner), eoff(c, b.qkv, 2 * inner),
+                           (long)Lt * 3 * inner, 3 * inner, e->dec.bias + (long)t * Lt, (long)Lt * Lt, e->dc_ctx, inner, B, H, t + 1, dk,
+                           c.ws()));
+    RC(proj_res(e->dc_ctx, inner, P[l.o].warena_off));
+    // cross attention over the encoder K/V projected at prefill
+    RC(klab_rmsnorm_fwd(h, W[l.ln1], e->dc_xn, c.dt, nullptr, e->dc_rstd, B, d, cfg.ln_eps, 0, 0, 0, 0.f, nullptr, 0, c.ws()));
+    RC(linear_fwd(c, e->dc_xn, B, d, P[l.cq].warena_off, inner, e->dc_q, inner, c.dt));
+    RC(klab_t5_decode_attn(c.dt, e->dc_q, inner, eoff(c, e->kv_all, (long)i * 2 * inner), eoff(c, e->kv_all, (long)i * 2 * inner + inner),
+                           (long)Le * kv_ld, kv_ld, nullptr, 0, e->dc_ctx, inner, B, H, Le, dk, c.ws()));
+    RC(proj_res(e->dc_ctx, inner, P[l.co].warena_off));
+    // feed forward
+    RC(klab_rmsnorm_fwd(h, W[l.ln2], e->dc_xn, c.dt, nullptr, e->dc_rstd, B, d, cfg.ln_eps, 0, 0, 0, 0.f, nullptr, 0, c.ws()));
+    RC(linear_fwd(c, e->dc_xn, B, d, P[l.wi].warena_off, ff, e->dc_hmid, ff, c.dt, nullptr, KLAB_ACT_RELU));
+    RC(proj_res(e->dc_hmid, ff, P[l.wo].warena_off));
+  }
+  RC(klab_rmsnorm_fwd(h, W[e->mi.dec_final], e->dc_out, c.dt, nullptr, e->dc_rstd, B, d, cfg.ln_eps, 0, 0, 0, 0.f, nullptr, 0, c.ws()));
+  {
+    const int V = cfg.vocab;
+    klab_gemm_args g = G0(c, B, V, d, e->dc_out, d, 1, woff(c, P[e->mi.shared].warena_off), d, 1, e->dc_logits, V, c.dt);
+    g.alpha = cfg.scale_decoder_outputs ? 1.f / sqrtf((float)d) : 1.f;  // HF/t5:1044-1045
+    RC(fwd_gemm(c, g, P[e->mi.shared].warena_off));
+  }
+  return 0;
 }
 
 // segment 0: LM head + decoder + shared embedding; 1: encoder; 2: Swin

@@ -896,6 +896,12 @@ static int dispatch_tile(GemmP& p, bool atomic_ok, hipStream_t s) {
       return wide ? dispatch_layout<T, 128, 128>(p, true, s) : dispatch_layout<T, 128, 64>(p, true, s);
     }
   }
+  {  // tuning aid: KLAB_GEMM_TILE = 1 (128x128) | 2 (128x64) | 3 (64x64) forces the tile of every unsplit product
+    static const int force = [] { const char* e = getenv("KLAB_GEMM_TILE"); return e ? atoi(e) : 0; }();
+    if (force == 1) return dispatch_layout<T, 128, 128>(p, false, s);
+    if (force == 2) return dispatch_layout<T, 128, 64>(p, false, s);
+    if (force == 3) return dispatch_layout<T, 64, 64>(p, false, s);
+  }
   if (tiles(128, 128) >= 240) return dispatch_layout<T, 128, 128>(p, false, s);
   if (tiles(128, 64) >= 240) return dispatch_layout<T, 128, 64>(p, false, s);
   if (atomic_ok && nt >= 16) {
@@ -910,6 +916,164 @@ static int dispatch_tile(GemmP& p, bool atomic_ok, hipStream_t s) {
     }
   }
   return dispatch_layout<T, 64, 64>(p, false, s);
+}
+
+// ---- fp8 forward GEMM (BASELINE configs[4]: "fp8 MFMA path") -----------------------------------------------------------
+// C[M,N] = epilogue(alpha * sa[m] * sb[n] * sum_k A8(m,k) B8(n,k)): both operands K-major OCP e4m3 bytes (gfx950's native
+// fp8), one dequantisation scale per ROW of each operand (per token / per output channel; per-tensor scaling is the special
+// case of equal entries), fp32 accumulation on v_mfma_f32_16x16x32_fp8_fp8.  The accumulator layout equals the bf16
+// kernels', so the whole epilogue family (bias, relu, gelu, dropout, residual, bf16 / f32 output) is shared with them.
+// Register-staged, double-buffered: 128-byte k-tiles (128 fp8 values), rows padded to 144 B in LDS, ds_read_b64 fragments.
+struct Fp8Scales { const float* sa; const float* sb; long sb_stride; };
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_fp8_kernel(GemmP p, Fp8Scales sc) {
+  constexpr int BK = 128;
+  constexpr int WTM = BM / 2, WTN = BN / 2, MI = WTM / 16, NI = WTN / 16;
+  constexpr int ABYTES = BM * ROWB, BBYTES = BN * ROWB, STAGE = ABYTES + BBYTES;
+  constexpr int ACH = BM * 8 / 256, BCH = BN * 8 / 256;  // 16-byte chunks per thread
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 1) * WTM, wn = (wave & 1) * WTN;
+  int bm0, bn0;
+  tile_of_block(p, BM, BN, blockIdx.x, bm0, bn0);
+  const char* A = reinterpret_cast<const char*>(p.A);
+  const char* B = reinterpret_cast<const char*>(p.B);
+  f32x4 va[ACH], vb[BCH];
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int c = 0; c < ACH; ++c) {
+      const int ch = tid + c * 256, r = ch >> 3, kc = ch & 7;
+      const int gr = bm0 + r, gk = k0 + kc * 16;
+      const bool ok = gr < p.M && gk < p.K;
+      f32x4 z = *reinterpret_cast<const f32x4*>(A + (long)(gr < p.M ? gr : p.M - 1) * p.lda + (gk < p.K ? gk : p.K - 16));
+      if (!ok) z = f32x4{0.f, 0.f, 0.f, 0.f};  // all-zero bytes = fp8 +0
+      va[c] = z;
+    }
+#pragma unroll
+    for (int c = 0; c < BCH; ++c) {
+      const int ch = tid + c * 256, r = ch >> 3, kc = ch & 7;
+      const int gr = bn0 + r, gk = k0 + kc * 16;
+      const bool ok = gr < p.N && gk < p.K;
+      f32x4 z = *reinterpret_cast<const f32x4*>(B + (long)(gr < p.N ? gr : p.N - 1) * p.ldb + (gk < p.K ? gk : p.K - 16));
+      if (!ok) z = f32x4{0.f, 0.f, 0.f, 0.f};
+      vb[c] = z;
+    }
+  };
+  auto store = [&](char* st) {
+#pragma unroll
+    for (int c = 0; c < ACH; ++c) { const int ch = tid + c * 256; *reinterpret_cast<f32x4*>(st + (ch >> 3) * ROWB + (ch & 7) * 16) = va[c]; }
+#pragma unroll
+    for (int c = 0; c < BCH; ++c) { const int ch = tid + c * 256; *reinterpret_cast<f32x4*>(st + ABYTES + (ch >> 3) * ROWB + (ch & 7) * 16) = vb[c]; }
+  };
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nt = (p.K + BK - 1) / BK;
+  load(0);
+  store(smem);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nt) load((t + 1) * BK);
+    const char* ta = smem + cur * STAGE + (wm + (lane & 15)) * ROWB + (lane >> 4) * 8;
+    const char* tb = smem + cur * STAGE + ABYTES + (wn + (lane & 15)) * ROWB + (lane >> 4) * 8;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      long af[MI], bfr[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const long*>(ta + i * 16 * ROWB + ks * 32);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) bfr[j] = *reinterpret_cast<const long*>(tb + j * 16 * ROWB + ks * 32);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < nt) store(smem + (cur ^ 1) * STAGE);
+    __syncthreads();
+  }
+  // dequantise: lane owns m = ... + (lane & 15), n = ... + (lane >> 4) * 4 + r
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = bm0 + wm + i * 16 + (lane & 15);
+    const float sam = sc.sa[m < p.M ? m : p.M - 1];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n0 = bn0 + wn + j * 16 + (lane >> 4) * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + r < p.N ? n0 + r : p.N - 1;
+        acc[i][j][r] *= sam * sc.sb[(long)n * sc.sb_stride];
+      }
+    }
+  }
+  float alpha = p.alpha;
+  if (p.alpha_dev) alpha *= p.alpha_dev[0];
+  staged_epilogue<bf16_t, BM, BN, MI, NI>(p, acc, alpha, smem, bm0, bn0, wm, wn, tid, lane);
+}
+
+__device__ __forceinline__ uint32_t pack4_fp8(float a, float b, float c, float d) {
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (uint32_t)w;
+}
+// one wave per row: amax -> scale = amax / 448 (e4m3 max), values / scale -> fp8 (round to nearest even, clamped)
+__device__ __forceinline__ void quant_row_fp8(const bf16_t* __restrict__ src, int K, uint8_t* __restrict__ dst, float* __restrict__ scale, int lane) {
+  constexpr int MAXV = 8;  // K <= 64 lanes * 8 values * MAXV = 4096
+  bf16x8 v[MAXV];
+  float amax = 0.f;
+#pragma unroll
+  for (int u = 0; u < MAXV; ++u) {
+    const int k = (u * 64 + lane) * 8;
+    v[u] = bf16x8{};
+    if (k < K) {
+      v[u] = *reinterpret_cast<const bf16x8*>(src + k);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf((float)v[u][e]));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+  const float sc = amax > 0.f ? amax * (1.f / 448.f) : 1.f;
+  const float inv = 1.f / sc;
+  if (lane == 0) *scale = sc;
+#pragma unroll
+  for (int u = 0; u < MAXV; ++u) {
+    const int k = (u * 64 + lane) * 8;
+    if (k < K) {
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf((float)v[u][e] * inv, -448.f), 448.f);
+      uint2 o2;
+      o2.x = pack4_fp8(f[0], f[1], f[2], f[3]);
+      o2.y = pack4_fp8(f[4], f[5], f[6], f[7]);
+      *reinterpret_cast<uint2*>(dst + k) = o2;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16_t* __restrict__ x, long ldx, int M, int K, uint8_t* __restrict__ x8,
+                                                             long ld8, float* __restrict__ scale, long scale_stride) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  quant_row_fp8(x + (long)row * ldx, K, x8 + (long)row * ld8, scale + (long)row * scale_stride, threadIdx.x & 63);
+}
+// every GEMM weight of the compute-dtype arena at once: desc[i] = {arena element offset, rows, K, first global row}
+struct QuantDesc { long off; long rows; long K; long row0; };
+__global__ __launch_bounds__(256) void quant_fp8_arena_kernel(const QuantDesc* __restrict__ d, int nd, long total_rows,
+                                                              const bf16_t* __restrict__ arena, uint8_t* __restrict__ w8,
+                                                              float* __restrict__ wscale) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= total_rows) return;
+  int lo = 0, hi = nd - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (d[mid].row0 <= row) lo = mid; else hi = mid - 1;
+  }
+  const long e = d[lo].off + (row - d[lo].row0) * d[lo].K;
+  quant_row_fp8(arena + e, (int)d[lo].K, w8 + e, wscale + (e >> 3), threadIdx.x & 63);
 }
 
 }  // namespace klab
@@ -976,19 +1140,9 @@ extern "C" int klab_gemm_grouped(const klab_gemm_args* list, int n, void* stream
   return flush();
 }
 
-extern "C" int klab_gemm(const klab_gemm_args* a, void* stream) {
-  using namespace klab;
-  if (!a || !a->A || !a->B || !a->C) return KLAB_ERR_BADARG;
-  if (a->M <= 0 || a->N <= 0 || a->K <= 0) return KLAB_OK;
-  const int vec = a->dtype == KLAB_BF16 ? 8 : 4;
-  // 16-byte vector staging: the contiguous dimension of each operand must be a multiple of `vec`
-  if (a->lda % vec || a->ldb % vec) return KLAB_ERR_UNSUPPORTED;
-  if (a->a_kmajor ? (a->K % vec) : (a->M % vec)) return KLAB_ERR_UNSUPPORTED;
-  if (a->b_kmajor ? (a->K % vec) : (a->N % vec)) return KLAB_ERR_UNSUPPORTED;
-  if (((uintptr_t)a->A & 15) || ((uintptr_t)a->B & 15) || ((uintptr_t)a->C & 15)) return KLAB_ERR_UNSUPPORTED;
-  if (a->dtype != KLAB_F32 && a->dtype != KLAB_BF16) return KLAB_ERR_BADARG;
-  if (a->c_dtype != KLAB_F32 && a->c_dtype != a->dtype) return KLAB_ERR_BADARG;
-  GemmP p;
+namespace klab {
+// klab_gemm_args -> kernel parameters + the epilogue variant (shared by the bf16 / f32 and the fp8 entry points)
+static void fill_gemmp(const klab_gemm_args* a, GemmP& p) {
   p.M = a->M; p.N = a->N; p.K = a->K;
   p.A = a->A; p.lda = a->lda; p.a_kmajor = a->a_kmajor;
   p.B = a->B; p.ldb = a->ldb; p.b_kmajor = a->b_kmajor;
@@ -1022,6 +1176,23 @@ extern "C" int klab_gemm(const klab_gemm_args* a, void* stream) {
     if (ablate < 0) { const char* e = getenv("KLAB_GEMM_ABLATE"); ablate = e ? atoi(e) : 0; }
     p.ablate = ablate;
   }
+}
+}  // namespace klab
+
+extern "C" int klab_gemm(const klab_gemm_args* a, void* stream) {
+  using namespace klab;
+  if (!a || !a->A || !a->B || !a->C) return KLAB_ERR_BADARG;
+  if (a->M <= 0 || a->N <= 0 || a->K <= 0) return KLAB_OK;
+  const int vec = a->dtype == KLAB_BF16 ? 8 : 4;
+  // 16-byte vector staging: the contiguous dimension of each operand must be a multiple of `vec`
+  if (a->lda % vec || a->ldb % vec) return KLAB_ERR_UNSUPPORTED;
+  if (a->a_kmajor ? (a->K % vec) : (a->M % vec)) return KLAB_ERR_UNSUPPORTED;
+  if (a->b_kmajor ? (a->K % vec) : (a->N % vec)) return KLAB_ERR_UNSUPPORTED;
+  if (((uintptr_t)a->A & 15) || ((uintptr_t)a->B & 15) || ((uintptr_t)a->C & 15)) return KLAB_ERR_UNSUPPORTED;
+  if (a->dtype != KLAB_F32 && a->dtype != KLAB_BF16) return KLAB_ERR_BADARG;
+  if (a->c_dtype != KLAB_F32 && a->c_dtype != a->dtype) return KLAB_ERR_BADARG;
+  GemmP p;
+  fill_gemmp(a, p);
   hipStream_t s = (hipStream_t)stream;
   if (a->name_tag == 1 && a->a_kmajor && a->b_kmajor) {
     if (a->dtype == KLAB_BF16) {
@@ -1038,4 +1209,59 @@ extern "C" int klab_gemm(const klab_gemm_args* a, void* stream) {
   const bool atomic_ok = a->atomic_ok && p.c_f32 && a->accumulate && !a->bias && !a->act && !a->aux && !a->residual && a->drop_p == 0.f;
   if (a->dtype == KLAB_BF16) return dispatch_tile<bf16_t>(p, atomic_ok, s);
   return dispatch_tile<float>(p, atomic_ok, s);
+}
+
+extern "C" int klab_quant_fp8_rows(const void* x, long ldx, int M, int K, void* x8, long ld8, float* row_scale, void* stream) {
+  using namespace klab;
+  if (!x || !x8 || !row_scale) return KLAB_ERR_BADARG;
+  if (M <= 0) return KLAB_OK;
+  if (K <= 0 || K > 4096 || (K & 7) || (ldx & 7) || (ld8 & 7) || ((uintptr_t)x & 15) || ((uintptr_t)x8 & 7)) return KLAB_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(quant_fp8_rows_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, M, K,
+                     (uint8_t*)x8, ld8, row_scale, 1L);
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+
+extern "C" int klab_quant_fp8_arena(const void* desc_dev, int ndesc, long total_rows, const void* arena_bf16, void* arena_fp8, float* scales,
+                                    void* stream) {
+  using namespace klab;
+  if (!desc_dev || !arena_bf16 || !arena_fp8 || !scales || ndesc <= 0) return KLAB_ERR_BADARG;
+  if (total_rows <= 0) return KLAB_OK;
+  hipLaunchKernelGGL(quant_fp8_arena_kernel, dim3((unsigned)((total_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const QuantDesc*)desc_dev, ndesc, total_rows, (const bf16_t*)arena_bf16, (uint8_t*)arena_fp8, scales);
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+
+extern "C" int klab_gemm_fp8(const klab_gemm_args* a, const float* a_row_scale, const float* b_row_scale, long b_scale_stride, void* stream) {
+  using namespace klab;
+  if (!a || !a->A || !a->B || !a->C || !a_row_scale || !b_row_scale) return KLAB_ERR_BADARG;
+  if (a->M <= 0 || a->N <= 0 || a->K <= 0) return KLAB_OK;
+  // A, B: fp8 bytes, K-major; everything else (C, aux, residual) as klab_gemm with dtype = KLAB_BF16
+  if (a->dtype != KLAB_BF16 || !a->a_kmajor || !a->b_kmajor || a->accumulate) return KLAB_ERR_UNSUPPORTED;
+  if ((a->K & 15) || (a->lda & 15) || (a->ldb & 15) || ((uintptr_t)a->A & 15) || ((uintptr_t)a->B & 15) || ((uintptr_t)a->C & 15))
+    return KLAB_ERR_UNSUPPORTED;
+  if (a->c_dtype != KLAB_F32 && a->c_dtype != KLAB_BF16) return KLAB_ERR_BADARG;
+  GemmP p;
+  fill_gemmp(a, p);
+  Fp8Scales sc{a_row_scale, b_row_scale, b_scale_stride};
+  hipStream_t s = (hipStream_t)stream;
+  auto tiles = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+  if (tiles(128, 128) >= 240) {
+    size_t lds = 2 * (size_t)(128 + 128) * ROWB;
+    const size_t epi = (size_t)epilogue_lds_bytes<128, 128>(p.c_f32);
+    if (epi > lds) lds = epi;
+    int rc = ensure_dyn_lds(reinterpret_cast<const void*>(gemm_fp8_kernel<128, 128>), lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((gemm_fp8_kernel<128, 128>), dim3((unsigned)tiles(128, 128)), dim3(256), lds, s, p, sc);
+  } else {
+    size_t lds = 2 * (size_t)(64 + 64) * ROWB;
+    const size_t epi = (size_t)epilogue_lds_bytes<64, 64>(p.c_f32);
+    if (epi > lds) lds = epi;
+    int rc = ensure_dyn_lds(reinterpret_cast<const void*>(gemm_fp8_kernel<64, 64>), lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((gemm_fp8_kernel<64, 64>), dim3((unsigned)tiles(64, 64)), dim3(256), lds, s, p, sc);
+  }
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
 }

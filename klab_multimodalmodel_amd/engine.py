@@ -115,6 +115,7 @@ ENGINE_SIGS = {
                           C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
                           C.POINTER(C.c_void_p), C.c_void_p], C.c_int),
     "klab_engine_forward": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_void_p], C.c_int),
+    "klab_engine_decode_step": ([C.c_void_p, C.c_int, C.c_void_p, C.c_void_p], C.c_int),
     "klab_engine_backward": ([C.c_void_p, C.c_int, C.c_void_p, C.c_void_p], C.c_int),
     "klab_engine_set_graph": ([C.c_void_p, C.c_int], C.c_int),
     "klab_engine_get_rng": ([C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p], C.c_int),
@@ -342,6 +343,10 @@ class Engine:
     def forward(self, pixels, src_ids, tgt_ids, training, seed, want_grad=True):
         L.check(self._lib.klab_engine_forward(self._h, pixels.data_ptr(), src_ids.data_ptr(), tgt_ids.data_ptr(), int(training),
                                               int(seed) & 0xFFFFFFFF, int(want_grad), L.stream_ptr()), "klab_engine_forward")
+
+    def decode_step(self, t, prev_tokens):
+        """decoder over position t (>= 1) only, self-attention K/V from the binding's cache; logits -> buffer("logits_step")"""
+        L.check(self._lib.klab_engine_decode_step(self._h, int(t), prev_tokens.data_ptr(), L.stream_ptr()), "klab_engine_decode_step")
 
     def backward(self, segment, dloss=None):
         L.check(self._lib.klab_engine_backward(self._h, segment, dloss.data_ptr() if dloss is not None else None, L.stream_ptr()),

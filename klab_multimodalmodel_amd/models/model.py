@@ -186,7 +186,8 @@ class MyModel(nn.Module):
             swin_sd, lang_sd, main_sd = _state_dicts or (None, None, None)
         self.swin_cfg, self.lang_cfg, self.main_cfg = swin_cfg, lang_cfg, main_cfg
         dt = dtype or os.environ.get("KLAB_DTYPE", "bf16")
-        self.compute_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32, torch.bfloat16: torch.bfloat16,
+        # "fp8" (BASELINE configs[4]): bf16 storage and backward, forward Linear GEMMs on fp8 MFMA with per-row scales
+        self.compute_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32, "fp8": "fp8", torch.bfloat16: torch.bfloat16,
                               torch.float32: torch.float32}[dt]
         self._engine = Engine(swin_cfg, lang_cfg, main_cfg, self.compute_dtype, bool(args.image_model_train))
         tied = {a: "shared.weight" for a in TIED_T5}
@@ -350,10 +351,12 @@ class MyModel(nn.Module):
         return self.generate(pixels, src)
 
     @torch.no_grad()
-    def generate(self, pixels, src, max_length=20):
-        """greedy decoding with HF's default generation settings (ref/models/model.py:28: max_length 20,
-        no sampling).  Swin, both encoders and the cross K/V run once; every further step re-runs only the decoder
-        stack and the LM head over the prefix (no per-token KV cache yet)."""
+    def generate(self, pixels, src, max_length=20, kv_cache=True):
+        """greedy decoding with HF's default generation settings (ref/models/model.py:28: max_length 20, no sampling).
+        Prefill = one evaluation-mode forward (Swin, both encoders, the cross K/V of all layers, decoder position 0); every
+        further token runs the decoder over ONE new position against the per-layer K/V cache (`klab_engine_decode_step`,
+        SURVEY §8 row f-3; HF/t5:308-332).  kv_cache=False keeps the round-1 form -- decoder + LM head over the whole prefix per
+        token -- as the cross-check of the cache."""
         B = src.shape[0]
         cfg = self.main_cfg
         steps = max_length - 1
@@ -362,12 +365,17 @@ class MyModel(nn.Module):
         was_training = self.transformer.training
         self.transformer.eval()
         try:
+            nxt = None
             for t in range(steps):
                 eng = self._engine_for(pixels, src, tgt)
-                eng.forward(pixels, src, tgt, training=(8 if t > 0 else 0) | (2 if t > 0 else 0), seed=self._seed_base, want_grad=False)
-                logits = eng.buffer("logits").view(B, steps, -1)[:, t].float()
+                if t == 0 or not kv_cache:
+                    eng.forward(pixels, src, tgt, training=(8 if t > 0 else 0) | (2 if t > 0 else 0), seed=self._seed_base, want_grad=False)
+                    logits = eng.buffer("logits").view(B, steps, -1)[:, t].float()
+                else:
+                    eng.decode_step(t, nxt)
+                    logits = eng.buffer("logits_step").float()
                 nxt = logits.argmax(-1)
-                nxt = torch.where(done, torch.full_like(nxt, cfg.pad_token_id), nxt)
+                nxt = torch.where(done, torch.full_like(nxt, cfg.pad_token_id), nxt).contiguous()
                 tgt[:, t] = nxt
                 done |= nxt == cfg.eos_token_id
                 if bool(done.all()):

@@ -40,6 +40,39 @@ def gemm(A, B, C_out, *, M, N, K, a_kmajor=True, b_kmajor=True, lda=None, ldb=No
     return C_out
 
 
+def quant_fp8_rows(x):
+    """bf16 [M, K] -> (uint8 e4m3 [M, K], f32 row scales [M])"""
+    import torch
+    lib = L.load()
+    M, K = x.shape
+    x8 = torch.empty(M, K, dtype=torch.uint8, device=x.device)
+    sc = torch.empty(M, dtype=torch.float32, device=x.device)
+    L.check(lib.klab_quant_fp8_rows(x.data_ptr(), x.stride(0), M, K, x8.data_ptr(), x8.stride(0), sc.data_ptr(), L.stream_ptr()),
+            "klab_quant_fp8_rows")
+    return x8, sc
+
+
+def gemm_fp8(A8, sa, B8, sb, C_out, *, alpha=1.0, bias=None, act=L.ACT_NONE, residual=None, drop_p=0.0, seed=None, tag=0):
+    """C[M,N] = epilogue(alpha * sa[m] sb[n] * A8 @ B8^T): A8 [M,K], B8 [N,K] e4m3 bytes (uint8), per-row scales"""
+    lib = L.load()
+    a = L.GemmArgs()
+    a.M, a.K = A8.shape
+    a.N = B8.shape[0]
+    a.dtype = L.BF16
+    a.A, a.lda, a.a_kmajor = A8.data_ptr(), A8.stride(0), 1
+    a.B, a.ldb, a.b_kmajor = B8.data_ptr(), B8.stride(0), 1
+    a.C, a.ldc, a.c_dtype = C_out.data_ptr(), C_out.stride(0), L.dtype_code(C_out.dtype)
+    a.alpha = alpha
+    a.bias = L.ptr(bias)
+    a.act = act
+    a.residual = L.ptr(residual)
+    a.ldr = residual.stride(0) if residual is not None else 0
+    a.r_dtype = L.dtype_code(residual.dtype) if residual is not None else 0
+    a.drop_p, a.seed_dev, a.drop_tag = drop_p, _seed_ptr(seed), tag
+    L.check(lib.klab_gemm_fp8(C.byref(a), sa.data_ptr(), sb.data_ptr(), 1, L.stream_ptr()), "klab_gemm_fp8")
+    return C_out
+
+
 def rmsnorm_fwd(x, w, y=None, y_f32=None, rstd=None, eps=1e-6, grp=0, grp_stride=0, off=0, drop_p=0.0, seed=None, tag=0):
     lib = L.load()
     rows, d = x.shape

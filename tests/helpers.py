@@ -44,3 +44,14 @@ def cosine(a, b):
     a = a.double().flatten()
     b = b.double().flatten()
     return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+def fp8_rows(x):
+    """per-row OCP e4m3 quantisation exactly as klab_quant_fp8_rows does it: scale = amax / 448 (1 for a zero row), values / scale
+    rounded to nearest-even e4m3.  Returns (dequantised float tensor, scales)."""
+    import torch
+    x = x.float()
+    amax = x.abs().amax(dim=-1, keepdim=True)
+    sc = torch.where(amax > 0, amax * (1.0 / 448.0), torch.ones_like(amax))
+    q = (x * (1.0 / sc)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float()
+    return q, sc

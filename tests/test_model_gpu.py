@@ -286,6 +286,38 @@ def test_generate_greedy_matches_oracle_argmax():
     assert torch.equal(out[:, 1].cpu(), parts["logits"][:, 0].argmax(-1))
 
 
+def test_generate_kv_cache_matches_prefix_recompute():
+    """per-token decoding over the K/V cache (klab_engine_decode_step: one new position per sample, the layer's
+    q|k|v buffer as the cache, cross K/V from the prefill) yields token for token what re-running the decoder over the whole
+    prefix yields -- fp32: identical ids and logits to 1e-5; bf16: logits within bf16 round-off (an argmax may flip on a near-tie
+    of random-weight logits, so ids are compared where the top-2 margin is clear)."""
+    for dtype in (torch.float32, torch.bfloat16):
+        m, g = build("tiny_b", dtype, False)
+        inp = g["inputs"]
+        pix, src = inp["pixel_values"].cuda(), inp["src_ids"].cuda()
+        a = m.generate(pix, src, max_length=12, kv_cache=True)
+        b = m.generate(pix, src, max_length=12, kv_cache=False)
+        assert a.shape == b.shape and int(a[0, 0]) == 0
+        if dtype == torch.float32:
+            assert torch.equal(a, b), (a, b)
+        # step-level check on a fixed prefix: logits of position t from the cache path vs the full-prefix path
+        B = src.shape[0]
+        steps = 11
+        tgt = torch.randint(2, g["t5_cfg"].vocab_size, (B, steps), generator=torch.Generator().manual_seed(1)).cuda()
+        eng = m._engine_for(pix, src, tgt)
+        m.transformer.eval()
+        with torch.no_grad():
+            eng.forward(pix, src, tgt, training=0, seed=m._seed_base, want_grad=False)
+            full = eng.buffer("logits").view(B, steps, -1).float().clone()  # teacher-forced logits of every position
+            # replay the same prefix through the cache: decoder input at t is tgt[:, t-1] (shift right)
+            eng.forward(pix, src, torch.zeros_like(tgt), training=0, seed=m._seed_base, want_grad=False)  # prefill with another target
+            for t in range(1, steps):
+                eng.decode_step(t, tgt[:, t - 1].contiguous())
+                step = eng.buffer("logits_step").float()
+                err = rel_l2(step.cpu(), full[:, t].cpu())
+                assert err < (1e-5 if dtype == torch.float32 else 2e-2), (dtype, t, err)
+
+
 def test_hipgraph_replay_matches_eager():
     """eager first step, captured second step, replayed afterwards: identical loss and gradients to the eager engine,
     with fresh input tensors every step (inputs are staged, so replay must not depend on their addresses)."""
@@ -815,3 +847,73 @@ def test_configs4_architecture_runs_at_full_width():
     assert bool(torch.isfinite(gs1).all()) and bool(torch.isfinite(gt1).all()) and float(gs1.norm()) > 0
     for a, b in ((gs1, gs2), (gt1, gt2)):
         assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.999 and abs(float(b.norm() / a.norm()) - 2.0) < 3e-2
+
+
+class _Fp8Linear(torch.autograd.Function):
+    """F.linear with both operands cast to per-row-scaled e4m3 in the forward pass and a full-precision backward: the
+    'oracle cast' of SURVEY §8(c)'s tolerance rule for the fp8 mode (what an ideal fp8 forward costs in accuracy)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        from tests.helpers import fp8_rows
+        ctx.save_for_backward(x, w)
+        ctx.has_b = b is not None
+        qx, sx = fp8_rows(x.reshape(-1, x.shape[-1]))
+        qw, sw = fp8_rows(w)
+        y = ((qx * sx) @ (qw * sw).t()).view(*x.shape[:-1], w.shape[0]).to(x.dtype)
+        return y + b if b is not None else y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        gx = g @ w
+        gw = g.reshape(-1, g.shape[-1]).t() @ x.reshape(-1, x.shape[-1])
+        return gx, gw, (g.reshape(-1, g.shape[-1]).sum(0) if ctx.has_b else None)
+
+
+@pytest.mark.gpu
+def test_fp8_forward_mode_within_twice_the_oracle_cast_error():
+    """dtype="fp8" (BASELINE configs[4]'s "fp8 MFMA path"): forward Linear GEMMs on e4m3 operands with per-row scales, bf16
+    everywhere else.  Stated tolerance: error against the fp32 oracle <= 2 x the error of the oracle itself with
+    its Linear operands cast to e4m3 (+ the bf16 mode's own allowance), gradient cosine >= 0.98."""
+    import torch.nn.functional as F
+    from klab_multimodalmodel_amd.engine import SwinConfig, T5Config
+    from klab_multimodalmodel_amd.models.model import MyModel
+    sw = SwinConfig(image_size=224, embed_dim=64, depths=(2, 2, 2, 2), num_heads=(2, 4, 8, 16), window_size=7)
+    t5 = T5Config(d_model=512, d_ff=2048, num_heads=8, num_layers=2, num_decoder_layers=2)
+    args = types.SimpleNamespace(result_dir="/tmp", language_model_name="-", image_model_name="-", image_model_train=True,
+                                 transformer_model_name="-")
+    m = MyModel(args, _configs=(sw, t5, t5), _seed=4, dtype="fp8")
+    O, sc, lc, mc, (ssd, lsd, msd) = _oracle_from_model(m)
+    m = m.to("cuda")
+    m.transformer.eval()
+    assert m._engine._cfg.dtype == 2
+    g = torch.Generator().manual_seed(8)
+    B, Ls, Lt = 2, 9, 32
+    pix = torch.randn(B, 3, 224, 224, generator=g)
+    src = torch.randint(2, 32000, (B, Ls), generator=g)
+    tgt = torch.randint(2, 32000, (B, Lt), generator=g)
+    loss = m({"pixel_values": pix.cuda()}, {"input_ids": src.cuda()}, {"input_ids": tgt.cuda()})
+    loss.backward()
+    msd = {k: v.requires_grad_(True) for k, v in msd.items()}
+    torch.set_num_threads(8)
+    ref = O.mymodel_forward(ssd, lsd, msd, sc, lc, mc, pix, src, tgt, training=False)
+    ref.backward()
+    real_linear = F.linear
+    try:  # the oracle's own fp8 cast: every F.linear of the path with e4m3 operands
+        O.F.linear = lambda x, w, b=None: _Fp8Linear.apply(x, w, b)
+        with torch.no_grad():
+            cast = O.mymodel_forward(ssd, lsd, {k: v.detach() for k, v in msd.items()}, sc, lc, mc, pix, src, tgt, training=False)
+    finally:
+        O.F.linear = real_linear
+    e_cast = abs(float(cast) - float(ref)) / abs(float(ref))
+    e_ours = abs(loss.item() - float(ref)) / abs(float(ref))
+    print("fp8 mode: loss", loss.item(), "oracle", float(ref), "oracle-with-e4m3-cast", float(cast), "rel err ours", e_ours, "cast", e_cast)
+    assert e_ours <= 2 * e_cast + 2e-3, (e_ours, e_cast)
+    a, b = [], []
+    for k, p in m.transformer.named_parameters():
+        a.append(p.grad.cpu().flatten())
+        b.append(msd[k].grad.flatten())
+    c = cosine(torch.cat(a), torch.cat(b))
+    print("fp8 mode: T5 grad cosine", c)
+    assert c > 0.98, c

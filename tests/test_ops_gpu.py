@@ -297,6 +297,39 @@ def test_t5_attention_dropout_fwd_bwd_consistent(ops):
     assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs))
 
 
+# ------------------------------------------------------------------------------------------ fp8 forward GEMM (configs[4])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 128), (4096, 1536, 512), (77, 64, 1024), (512, 32128, 256), (130, 130, 4096)])
+def test_fp8_gemm_matches_emulated_quantisation(ops, M, N, K):
+    """klab_quant_fp8_rows + klab_gemm_fp8 (OCP e4m3 operands, per-row scales, fp32 accumulation) against the same quantisation
+    emulated in torch: products of e4m3 values are exact in fp32, so only the accumulation order differs."""
+    from tests.helpers import fp8_rows
+    a = rnd(M, K, seed=1, scale=2.0).to(torch.bfloat16)
+    b = rnd(N, K, seed=2, scale=0.05).to(torch.bfloat16)
+    a[3] = 0  # an all-zero row: scale 1, no NaN
+    qa, sa = fp8_rows(a)
+    qb, sb = fp8_rows(b)
+    a8, sa_k = ops.quant_fp8_rows(dev(a))
+    b8, sb_k = ops.quant_fp8_rows(dev(b))
+    assert rel_l2(sa_k.cpu(), sa.view(-1)) < 1e-6 and rel_l2(sb_k.cpu(), sb.view(-1)) < 1e-6
+    deq = a8.cpu().view(torch.float8_e4m3fn).float()
+    assert float((deq != qa).float().mean()) < 1e-3  # bit-identical bytes but for ties of the 1/scale product
+    bias = rnd(N, seed=3)
+    ref = (qa @ qb.t()) * sa * sb.view(1, -1)
+    for out_dt in (torch.bfloat16, torch.float32):
+        c = torch.empty(M, N, device="cuda", dtype=out_dt)
+        ops.gemm_fp8(a8, sa_k, b8, sb_k, c)
+        assert rel_l2(c.float().cpu(), ref) < (4e-3 if out_dt == torch.bfloat16 else 2e-4)
+    c = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.gemm_fp8(a8, sa_k, b8, sb_k, c, alpha=0.5, bias=dev(bias), act=ops.L.ACT_RELU)
+    assert rel_l2(c.float().cpu(), torch.relu(0.5 * ref + bias)) < 4e-3
+    res = rnd(M, N, seed=4)
+    c32 = torch.empty(M, N, device="cuda")
+    ops.gemm_fp8(a8, sa_k, b8, sb_k, c32, residual=dev(res))
+    assert rel_l2(c32.cpu(), ref + res) < 2e-4
+    # against the unquantised product: the e4m3 round-off itself (2^-4 relative per element, averaged over K)
+    assert rel_l2(ref, a.float() @ b.float().t()) < 6e-2
+
+
 # ------------------------------------------------------------------------------------------ Swin attention
 def _swin_attn_ref(qkv, bias, logit_scale, B, R, w, shift, H, C):
     """HF/swinv2:389-455 + :652-690 on a fused qkv [B*R*R, 3C] (fp32 torch)."""

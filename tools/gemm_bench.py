@@ -13,6 +13,11 @@ SHAPES = [  # name, M, N, K, a_kmajor, b_kmajor, atomic
     ("lmhead dgrad", 4096, 512, 32128, True, False, True),
     ("lmhead wgrad", 32128, 512, 4096, False, False, True),
     ("qkv fwd", 4096, 1536, 512, True, True, False),
+    ("qkv fwd enc", 3712, 1536, 512, True, True, False),
+    ("o fwd enc", 3712, 512, 512, True, True, False),
+    ("wi fwd enc", 3712, 2048, 512, True, True, False),
+    ("wo fwd enc", 3712, 512, 2048, True, True, False),
+    ("o dgrad", 4096, 512, 512, True, False, False),
     ("o fwd", 4096, 512, 512, True, True, False),
     ("wi fwd", 4096, 2048, 512, True, True, False),
     ("wo fwd", 4096, 512, 2048, True, True, False),
