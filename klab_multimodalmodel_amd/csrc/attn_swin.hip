@@ -14,6 +14,7 @@
 // swin_qkv_attn_fused below (49-token windows padded to 64) and, backward, the gather -> t5_attn_bwd_mfma<32> -> scatter
 // sequence of swin_attn_bwd_mfma.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -758,7 +759,7 @@ __global__ __launch_bounds__(256) void cpb_mlp_bwd_kernel(const float* __restric
 // into a per-window table), P recomputed from the forward's LSE, dS stored for the bias gradient; (3) back to token order
 // through the Jacobian of x / |x| and the logit-scale gradient.  Every pass addresses whole 64-byte head slices with 4 lanes.
 struct SwinBwdWs {
-  size_t g, dow, ow, dg, invn, scale, ds, biasw, total;
+  size_t g, dow, ow, dg, invn, scale, ds, biasw, dtp, total;
 };
 __host__ inline SwinBwdWs swin_bwd_ws(int B, int R, int w, int H, int C) {
   const size_t M = (size_t)B * R * R, n = (size_t)w * w, nW = (size_t)(R / w) * (R / w);
@@ -771,8 +772,11 @@ __host__ inline SwinBwdWs swin_bwd_ws(int B, int R, int w, int H, int C) {
   o.dg = off; off += al(M * 3 * C * 2);
   o.invn = off; off += al(M * H * 2 * 4);
   o.scale = off; off += al((size_t)H * 4);
-  o.ds = off; off += al((size_t)B * nW * H * n * 64 * 2);
-  o.biasw = off; off += al(nW * H * n * n * 4);
+  const bool large = n > 64;  // streaming kernels: no dS scratch, no per-window bias+mask tensor
+  o.ds = off; off += large ? 0 : al((size_t)B * nW * H * n * 64 * 2);
+  o.biasw = off; off += large ? 0 : al(nW * H * n * n * 4);
+  // large windows: per-workgroup partials of d(bias table), [B*nW * ceil(n/64), H, (2w-1)^2] f32
+  o.dtp = off; off += large ? al((size_t)B * nW * ((n + 63) / 64) * H * (size_t)(2 * w - 1) * (2 * w - 1) * 4) : 0;
   o.total = off;
   return o;
 }
@@ -821,6 +825,34 @@ __global__ __launch_bounds__(256) void swin_bwd_gather_kernel(SwinBwdP p) {
   *reinterpret_cast<bf16x8*>(p.dow + rw * C + c8 * 8) = d;
   *reinterpret_cast<bf16x8*>(p.ow + rw * C + c8 * 8) = o;
   if ((c8 & 3) == 0) *reinterpret_cast<float2*>(p.invn + (rw * p.H + h) * 2) = make_float2(iq, ik);
+}
+
+// forward flavour of the gather: window-major unit-q | unit-k | v only (the streaming forward of large windows)
+__global__ __launch_bounds__(256) void swin_fwd_gather_kernel(SwinBwdP p) {
+  const int C = p.C, C8 = C >> 3, n = p.w * p.w, nWr = p.R / p.w, nW = nWr * nWr;
+  const long M = (long)p.B * p.R * p.R;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x == 0 && (int)threadIdx.x < p.H) p.scale[threadIdx.x] = __expf(fminf(p.logit_scale[threadIdx.x], 4.6051701859880914f));
+  if (idx >= M * C8) return;
+  const long rw = idx / C8;
+  const int c8 = (int)(idx % C8);
+  const int t = swin_token_of_row(rw, n, nW, nWr, p.w, p.R, p.shift);
+  const bf16_t* src = p.qkv + (long)t * 3 * C + c8 * 8;
+  bf16x8 q = *reinterpret_cast<const bf16x8*>(src);
+  bf16x8 k = *reinterpret_cast<const bf16x8*>(src + C);
+  const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + 2 * C);
+  float sq = 0.f, sk = 0.f;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) { const float a = (float)q[u], b = (float)k[u]; sq += a * a; sk += b * b; }
+  sq += __shfl_xor(sq, 1, 64); sk += __shfl_xor(sk, 1, 64);
+  sq += __shfl_xor(sq, 2, 64); sk += __shfl_xor(sk, 2, 64);
+  const float iq = 1.f / fmaxf(sqrtf(sq), 1e-12f), ik = 1.f / fmaxf(sqrtf(sk), 1e-12f);  // F.normalize eps (HF/swinv2:413)
+#pragma unroll
+  for (int u = 0; u < 8; ++u) { q[u] = (bf16_t)((float)q[u] * iq); k[u] = (bf16_t)((float)k[u] * ik); }
+  bf16_t* dst = p.g + rw * 3 * C + c8 * 8;
+  *reinterpret_cast<bf16x8*>(dst) = q;
+  *reinterpret_cast<bf16x8*>(dst + C) = k;
+  *reinterpret_cast<bf16x8*>(dst + 2 * C) = v;
 }
 
 // bias + shift mask per window: biasw[win, h, i, j] = bias[h, i, j] - 200 * (region(i) != region(j))  (HF/swinv2:433-436, twice)
@@ -881,6 +913,9 @@ __global__ __launch_bounds__(256) void swin_bwd_scatter_kernel(SwinBwdP p) {
 }
 
 int t5_attn_bwd_mfma_dispatch(const klab_attn_args* a, hipStream_t s);  // attn_t5_mfma.hip
+int swin_flash_dispatch(const void* g, long ldg, int C, void* otok, long ldot, float* lse, int Bt, int H, int n, const float* scale,
+                        const float* btab, float* dbtab, float* dbtab_part, int w, int R, int shift, int nW, const void* ow,
+                        const void* dow, void* dg, int which, hipStream_t s);
 int dbias_reduce_dispatch(const void* ds_ws, float* dbias, int nbatch, int H, int Lq, int Lk, hipStream_t s);
 
 }  // namespace klab
@@ -930,10 +965,16 @@ static int swin_args_ok(const klab_swin_attn_args* a) {
   return KLAB_OK;
 }
 
+static bool swin_flash_ok(int dtype, int w, int H, int C);
+static int swin_attn_flash(const klab_swin_attn_args* a, bool backward, hipStream_t s);
+
 extern "C" int klab_swin_attn_fwd(const klab_swin_attn_args* a, void* stream) {
   int rc = swin_args_ok(a);
   if (rc) return rc;
-  if (swin_use_large(a)) return swin_attn_large_dispatch(a, false, (hipStream_t)stream);
+  if (swin_use_large(a)) {
+    if (a->bwd_ws && a->bias_table && !a->bias && a->lse && swin_flash_ok(a->dtype, a->w, a->H, a->C)) return swin_attn_flash(a, false, (hipStream_t)stream);
+    return swin_attn_large_dispatch(a, false, (hipStream_t)stream);
+  }
   SwinAttnP p{a->qkv, a->ctx, a->bias, a->logit_scale, a->lse, a->B, a->R, a->w, a->shift, a->H, a->C, nullptr, nullptr, nullptr, nullptr};
   const int hd = a->C / a->H;
   hipStream_t s = (hipStream_t)stream;
@@ -954,10 +995,45 @@ extern "C" int klab_swin_attn_fwd(const klab_swin_attn_args* a, void* stream) {
 }
 
 static bool swin_bwd_mfma_ok(int dtype, int w, int H, int C) { return dtype == KLAB_BF16 && C == H * 32 && w * w <= 64 && H <= 64; }
+// windows of more than 64 tokens on the matrix cores: streaming kernels over window-major copies (bf16, head dim 32, bias table)
+static bool swin_flash_ok(int dtype, int w, int H, int C) {
+  static const bool on = [] { const char* e = getenv("KLAB_SWIN_FLASH"); return !e || atoi(e) != 0; }();
+  return on && dtype == KLAB_BF16 && C == H * 32 && w * w > 64 && H <= 64 && (C & 7) == 0;
+}
 
 extern "C" size_t klab_swin_attn_bwd_ws_bytes(int dtype, int B, int R, int w, int H, int C) {
-  if (B <= 0 || R <= 0 || w <= 0 || R % w || !swin_bwd_mfma_ok(dtype, w, H, C)) return 0;
+  if (B <= 0 || R <= 0 || w <= 0 || R % w) return 0;
+  if (!swin_bwd_mfma_ok(dtype, w, H, C) && !swin_flash_ok(dtype, w, H, C)) return 0;
   return swin_bwd_ws(B, R, w, H, C).total;
+}
+
+static int swin_attn_flash(const klab_swin_attn_args* a, bool backward, hipStream_t s) {
+  const SwinBwdWs L = swin_bwd_ws(a->B, a->R, a->w, a->H, a->C);
+  if (a->bwd_ws_bytes < L.total) return KLAB_ERR_BADARG;
+  char* ws = (char*)a->bwd_ws;
+  const int n = a->w * a->w, nW = (a->R / a->w) * (a->R / a->w), C = a->C, H = a->H;
+  SwinBwdP p{(const bf16_t*)a->qkv, (const bf16_t*)a->ctx, (const bf16_t*)a->dctx, (bf16_t*)a->dqkv,
+             (bf16_t*)(ws + L.g), (bf16_t*)(ws + L.dow), (bf16_t*)(ws + L.ow), (const bf16_t*)(ws + L.dg), (float*)(ws + L.invn),
+             (float*)(ws + L.scale), a->logit_scale, a->dlogit_scale, a->B, a->R, a->w, a->shift, H, C};
+  const long work = (long)a->B * a->R * a->R * (C / 8);
+  const unsigned nb = (unsigned)((work + 255) / 256);
+  if (!backward) {
+    hipLaunchKernelGGL(swin_fwd_gather_kernel, dim3(nb), dim3(256), 0, s, p);
+    KLAB_LAUNCH_CHECK();
+    return swin_flash_dispatch(ws + L.g, 3L * C, C, a->ctx, C, a->lse, a->B * nW, H, n, (const float*)(ws + L.scale), a->bias_table, nullptr,
+                               nullptr, a->w, a->R, a->shift, nW, nullptr, nullptr, nullptr, 0, s);
+  }
+  hipLaunchKernelGGL(swin_bwd_gather_kernel, dim3(nb), dim3(256), 0, s, p);
+  KLAB_LAUNCH_CHECK();
+  for (int which = 1; which <= 2; ++which) {
+    const int rc = swin_flash_dispatch(ws + L.g, 3L * C, C, nullptr, 0, a->lse, a->B * nW, H, n, (const float*)(ws + L.scale), a->bias_table,
+                                       a->dbias_table, (float*)(ws + L.dtp), a->w, a->R, a->shift, nW, ws + L.ow, ws + L.dow, ws + L.dg,
+                                       which, s);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(swin_bwd_scatter_kernel, dim3(nb), dim3(256), 0, s, p);
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
 }
 
 static int swin_attn_bwd_mfma(const klab_swin_attn_args* a, hipStream_t s) {
@@ -1001,7 +1077,10 @@ extern "C" int klab_swin_attn_bwd(const klab_swin_attn_args* a, void* stream) {
   int rc = swin_args_ok(a);
   if (rc) return rc;
   if (!a->dctx || !a->dqkv || !a->lse) return KLAB_ERR_BADARG;
-  if (swin_use_large(a)) return swin_attn_large_dispatch(a, true, (hipStream_t)stream);
+  if (swin_use_large(a)) {
+    if (a->bwd_ws && a->bias_table && !a->bias && swin_flash_ok(a->dtype, a->w, a->H, a->C)) return swin_attn_flash(a, true, (hipStream_t)stream);
+    return swin_attn_large_dispatch(a, true, (hipStream_t)stream);
+  }
   SwinAttnP p{a->qkv, a->ctx, a->bias, a->logit_scale, a->lse, a->B, a->R, a->w, a->shift, a->H, a->C,
               a->dctx, a->dqkv, a->dbias, a->dlogit_scale};
   const int hd = a->C / a->H;

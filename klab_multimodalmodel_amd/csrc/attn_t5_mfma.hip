@@ -14,6 +14,8 @@
 //   ds_read_b128 fragments) and, where a product contracts over the sequence index, a transposed-read image
 //   (TrImg: 8-row groups displaced by 32 dwords, conflict-free ds_read_b64_tr_b16).
 #include <math.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 #include "klab_mm.h"
@@ -45,7 +47,7 @@ template <int COLS> struct TrImg {  // rows = contraction index, columns = COLS 
   static constexpr int PITCHB = PD * 4;
   static constexpr int GROUPB = (8 * PD + 32) * 4;
   __device__ static __forceinline__ int off(int row, int col) { return (row >> 3) * GROUPB + (row & 7) * PITCHB + col * 2; }
-  static size_t bytes(int rows) { return (size_t)((rows + 7) / 8) * GROUPB; }
+  __host__ __device__ static constexpr size_t bytes(int rows) { return (size_t)((rows + 7) / 8) * GROUPB; }
 };
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
@@ -466,6 +468,494 @@ __global__ __launch_bounds__(256) void dbias_reduce_kernel(const bf16_t* __restr
   else if (b1 > b0) atomicAdd(dbias + idx, a);
 }
 
+// ================================================================================================
+// Streaming ("flash") forms of the same three products, for sequences whose images do not fit one workgroup's LDS:
+// Swin-V2 windows of 576 / 144 tokens (384 px / window 24, head dim 32) and the T5-large encoder's Le = 153 (head dim 64).
+// Same swapped / unswapped MFMA tile constructions as above; what changes is the loop structure:
+//   flash_fwd    : a workgroup owns 64 queries (one 16-query tile per wave, Q fragments in registers) and streams the keys
+//                  through LDS in blocks of 64 (K row image + V transposed-read image) with an online softmax;
+//   flash_bwd_dq : same ownership; per key block the K and V row images and the K transposed image; P from the forward's LSE,
+//                  delta = dO . O from the rows already in registers;
+//   flash_bwd_dkv: a workgroup owns 64 keys (K, V fragments in registers) and streams the queries (Q, dO row + transposed
+//                  images, delta, LSE per block).
+// Bias forms (template BIAS): 0 none; 1 dense [bias_mod | 1][H, Lq, Lk] (T5 relative-position bias, d bias through the dS
+// scratch as above); 2 Swin-V2: looked up per score in the head's column of the (2w-1)^2 x H table held in LDS, plus the
+// shifted-window mask from the tokens' coordinates -- index(i, j) = code(i) - code(j) + 2w(w-1), code(t) = y_t (2w-1) + x_t
+// (HF/swinv2:480-490, 433-436); d(table) accumulated in LDS (ds_add_f32) and flushed with one global atomic per entry.
+// ================================================================================================
+struct FlashP {
+  const bf16_t* q; long ldq; const bf16_t* k; long ldk; const bf16_t* v; long ldv;
+  bf16_t* o; long ldo;        // forward: output rows (bt*Lq + i); backward: the forward's output (delta)
+  bf16_t* otok; long ldot;    // forward, BIAS 2: also/instead written in TOKEN order (row = source token of (bt, i)); may be null
+  float* lse;                 // [Bt, H, Lq]
+  int Bt, H, Lq, Lk;
+  const float* score_scale;   // [H] or null
+  const float* bias; int bias_mod;
+  const float* btab; float* dbtab; int w, R, shift, nW;
+  float* dbtab_part;  // [Bt * ceil(Lq/64), H, ntab]: every d-q workgroup stores its table partial here (plain stores; one
+                      // reduction afterwards) -- flushing 4608 workgroups x 2209 entries with global atomics onto 8.8 k
+                      // addresses cost more than the whole rest of the kernel
+  float p; const uint32_t* seed; uint32_t tag;
+  const bf16_t* dout; long lddo;
+  bf16_t* dq; long lddq; bf16_t* dkk; long lddk; bf16_t* dv; long lddv;
+  bf16_t* ds_ws;
+};
+
+__device__ __forceinline__ int flash_region(int s, int R, int w, int shift) { return (s >= R - w) + (s >= R - shift); }
+// window-local index i of window `win` -> bias code and mask region (window-major sequence bt = b*nW + win)
+__device__ __forceinline__ void flash_tok(const FlashP& p, int win, int i, int& code, int& reg) {
+  const int w = p.w, nWr = p.R / w;
+  const int iy = i / w, ix = i - iy * w;
+  code = iy * (2 * w - 1) + ix;
+  reg = p.shift > 0 ? flash_region((win / nWr) * w + iy, p.R, w, p.shift) * 3 + flash_region((win % nWr) * w + ix, p.R, w, p.shift) : 0;
+}
+__device__ __forceinline__ long flash_token_row(const FlashP& p, int bt, int i) {
+  const int w = p.w, nWr = p.R / w, win = bt % p.nW, b = bt / p.nW;
+  const int ys = (win / nWr) * w + i / w, xs = (win % nWr) * w + i % w;
+  return ((long)b * p.R + (ys + p.shift) % p.R) * p.R + (xs + p.shift) % p.R;
+}
+
+constexpr int FKB = 64;  // rows per streamed block
+
+// rows [r0, r0 + 64) of sequence bt (zero beyond L) -> row image and / or transposed-read image, local row index
+template <int DK, int DKP, bool ROWIMG, bool TRIMG>
+__device__ __forceinline__ void stage_blk(const bf16_t* __restrict__ g, long ld, long seq_row0, int h, int r0, int L, char* rowimg, int pitchB,
+                                          char* trimg) {
+  constexpr int CPR = DKP / 8;
+  for (int ch = threadIdx.x; ch < FKB * CPR; ch += 256) {
+    const int r = ch / CPR, c = (ch % CPR) * 8;
+    bf16x8 v = {};
+    if (r0 + r < L && c < DK) v = *reinterpret_cast<const bf16x8*>(g + (seq_row0 + r0 + r) * ld + (long)h * DK + c);
+    if (ROWIMG) *reinterpret_cast<bf16x8*>(rowimg + r * pitchB + c * 2) = v;
+    if (TRIMG) *reinterpret_cast<bf16x8*>(trimg + TrImg<DKP>::off(r, c)) = v;
+  }
+}
+
+template <int DK, int BIAS>
+__global__ __launch_bounds__(256) void flash_fwd_kernel(FlashP p) {
+  constexpr int KS = (DK + 31) / 32, DKP = KS * 32, DT = DK / 16, KPITCH = DKP * 2 + 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Kr = smem;
+  char* Vt = Kr + FKB * KPITCH;
+  int* kcode = reinterpret_cast<int*>(Vt + TrImg<DKP>::bytes(FKB));
+  int* kreg = kcode + FKB;
+  float* tab = reinterpret_cast<float*>(kreg + FKB);
+  const int Lq = p.Lq, Lk = p.Lk;
+  const int bt = blockIdx.y / p.H, h = blockIdx.y % p.H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+  const long qrow0 = (long)bt * Lq, krow0 = (long)bt * Lk;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  const bool active = q0 < Lq;
+  const int q = q0 + (lane & 15);
+  const int qc = q < Lq ? q : Lq - 1;
+  const int win = BIAS == 2 ? bt % p.nW : 0;
+  int qreg = 0, coff = 0;
+  if constexpr (BIAS == 2) {
+    const int ntab = (2 * p.w - 1) * (2 * p.w - 1);
+    for (int t = threadIdx.x; t < ntab; t += 256) tab[t] = p.btab[(long)t * p.H + h];
+    int qcode;
+    flash_tok(p, win, qc, qcode, qreg);
+    coff = qcode + 2 * p.w * (p.w - 1);
+  }
+  bf16x8 qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int c = ks * 32 + g * 8;
+    bf16x8 v = {};
+    if (c < DK) v = *reinterpret_cast<const bf16x8*>(p.q + (qrow0 + qc) * p.ldq + (long)h * DK + c);
+    qf[ks] = v;
+  }
+  const float sscale = p.score_scale ? p.score_scale[h] : 1.f;
+  const float* brow = nullptr;
+  if constexpr (BIAS == 1) brow = p.bias + (p.bias_mod > 0 ? (long)(bt % p.bias_mod) * p.H * Lq * Lk : 0L) + ((long)h * Lq + qc) * Lk;
+  const DropCtx dc = drop_slab(make_drop(p.seed, p.tag, p.p), (uint32_t)(bt * p.H + h));
+  float m = -INFINITY, l = 0.f;
+  f32x4 o[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int k0 = 0; k0 < Lk; k0 += FKB) {
+    __syncthreads();
+    stage_blk<DK, DKP, true, false>(p.k, p.ldk, krow0, h, k0, Lk, Kr, KPITCH, nullptr);
+    stage_blk<DK, DKP, false, true>(p.v, p.ldv, krow0, h, k0, Lk, nullptr, 0, Vt);
+    if constexpr (BIAS == 2) {
+      if (threadIdx.x < FKB) {
+        const int kk = k0 + threadIdx.x;
+        int c = 0, r = -1;
+        if (kk < Lk) flash_tok(p, win, kk, c, r);
+        kcode[threadIdx.x] = c; kreg[threadIdx.x] = r;
+      }
+    }
+    __syncthreads();
+    if (!active) continue;
+    f32x4 s[4];
+    float mb = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Kr, KPITCH, t * 16, ks, lane), qf[ks], s[t], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kl = t * 16 + g * 4 + r, key = k0 + kl;
+        float x = -INFINITY;
+        if (key < Lk) {
+          x = s[t][r] * sscale;
+          if constexpr (BIAS == 1) x += brow[key];
+          if constexpr (BIAS == 2) { x += tab[coff - kcode[kl]]; if (kreg[kl] != qreg) x += -200.f; }
+        }
+        s[t][r] = x;
+        mb = fmaxf(mb, x);
+      }
+    }
+    mb = fmaxf(mb, __shfl_xor(mb, 16, 64));
+    mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
+    const float mn = fmaxf(m, mb);
+    const float corr = __expf(m - mn);
+    float sum = 0.f;
+    const uint32_t dbase = (uint32_t)qc * (uint32_t)Lk + (uint32_t)k0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __expf(s[t][r] - mn);
+        sum += e;
+        s[t][r] = e * drop_mult32(dc, dbase + t * 16 + g * 4 + r);
+      }
+    l = l * corr + sum;
+    m = mn;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) { o[dt][0] *= corr; o[dt][1] *= corr; o[dt][2] *= corr; o[dt][3] *= corr; }
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      const bf16x8 pf = pack8(s[2 * sidx], s[2 * sidx + 1]);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DKP>(Vt, sidx * 32, dt * 16, lane), pf, o[dt], 0, 0, 0);
+    }
+  }
+  if (!active) return;
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.f / l;
+  if (q < Lq) {
+    if (g == 0 && p.lse) p.lse[((long)bt * p.H + h) * Lq + q] = m + __logf(l);
+    const long trow = (BIAS == 2 && p.otok) ? flash_token_row(p, bt, q) : 0;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const int d = dt * 16 + g * 4;
+      const bf16x4 ov = bf16x4{(bf16_t)(o[dt][0] * inv), (bf16_t)(o[dt][1] * inv), (bf16_t)(o[dt][2] * inv), (bf16_t)(o[dt][3] * inv)};
+      if (p.o) *reinterpret_cast<bf16x4*>(p.o + (qrow0 + q) * p.ldo + (long)h * DK + d) = ov;
+      if (BIAS == 2 && p.otok) *reinterpret_cast<bf16x4*>(p.otok + trow * p.ldot + (long)h * DK + d) = ov;
+    }
+  }
+}
+
+template <int DK, int BIAS>
+__global__ __launch_bounds__(256) void flash_bwd_dq_kernel(FlashP p) {
+  constexpr int KS = (DK + 31) / 32, DKP = KS * 32, DT = DK / 16, KPITCH = DKP * 2 + 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Kr = smem;
+  char* Vr = Kr + FKB * KPITCH;
+  char* Kt = Vr + FKB * KPITCH;
+  int* kcode = reinterpret_cast<int*>(Kt + TrImg<DKP>::bytes(FKB));
+  int* kreg = kcode + FKB;
+  float* tab = reinterpret_cast<float*>(kreg + FKB);
+  const int ntab = BIAS == 2 ? (2 * p.w - 1) * (2 * p.w - 1) : 0;
+  float* dtab = tab + ntab;
+  const int Lq = p.Lq, Lk = p.Lk, Lkp = (Lk + 31) & ~31;
+  const int bt = blockIdx.y / p.H, h = blockIdx.y % p.H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+  const long qrow0 = (long)bt * Lq, krow0 = (long)bt * Lk;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  const bool active = q0 < Lq;
+  const int q = q0 + (lane & 15);
+  const int qc = q < Lq ? q : Lq - 1;
+  const int win = BIAS == 2 ? bt % p.nW : 0;
+  int qreg = 0, coff = 0;
+  if constexpr (BIAS == 2) {
+    for (int t = threadIdx.x; t < ntab; t += 256) tab[t] = p.btab[(long)t * p.H + h];
+    // d(table): one private copy per 16-lane group.  Within a group the 16 lanes are 16 consecutive queries against ONE key
+    // offset: distinct table entries; across groups (keys 4 apart) entries i - j repeat -- a shared copy measured 4x slower.
+    for (int t = threadIdx.x; t < 4 * ntab; t += 256) dtab[t] = 0.f;
+    int qcode;
+    flash_tok(p, win, qc, qcode, qreg);
+    coff = qcode + 2 * p.w * (p.w - 1);
+  }
+  bf16x8 qf[KS], dof[KS];
+  float delta = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int c = ks * 32 + g * 8;
+    bf16x8 vq = {}, vd = {}, vo = {};
+    if (c < DK) {
+      vq = *reinterpret_cast<const bf16x8*>(p.q + (qrow0 + qc) * p.ldq + (long)h * DK + c);
+      vd = *reinterpret_cast<const bf16x8*>(p.dout + (qrow0 + qc) * p.lddo + (long)h * DK + c);
+      vo = *reinterpret_cast<const bf16x8*>(p.o + (qrow0 + qc) * p.ldo + (long)h * DK + c);
+    }
+    qf[ks] = vq; dof[ks] = vd;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) delta += (float)vd[u] * (float)vo[u];
+  }
+  delta += __shfl_xor(delta, 16, 64);
+  delta += __shfl_xor(delta, 32, 64);
+  const float lq = p.lse[((long)bt * p.H + h) * Lq + qc];
+  const float sscale = p.score_scale ? p.score_scale[h] : 1.f;
+  const float* brow = nullptr;
+  if constexpr (BIAS == 1) brow = p.bias + (p.bias_mod > 0 ? (long)(bt % p.bias_mod) * p.H * Lq * Lk : 0L) + ((long)h * Lq + qc) * Lk;
+  bf16_t* dsrow = (BIAS == 1 && p.ds_ws && q < Lq) ? p.ds_ws + (((long)bt * p.H + h) * Lq + q) * Lkp : nullptr;
+  const DropCtx dc = drop_slab(make_drop(p.seed, p.tag, p.p), (uint32_t)(bt * p.H + h));
+  f32x4 acc[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int k0 = 0; k0 < Lk; k0 += FKB) {
+    __syncthreads();
+    stage_blk<DK, DKP, true, true>(p.k, p.ldk, krow0, h, k0, Lk, Kr, KPITCH, Kt);
+    stage_blk<DK, DKP, true, false>(p.v, p.ldv, krow0, h, k0, Lk, Vr, KPITCH, nullptr);
+    if constexpr (BIAS == 2) {
+      if (threadIdx.x < FKB) {
+        const int kk = k0 + threadIdx.x;
+        int c = 0, r = -1;
+        if (kk < Lk) flash_tok(p, win, kk, c, r);
+        kcode[threadIdx.x] = c; kreg[threadIdx.x] = r;
+      }
+    }
+    __syncthreads();
+    if (!active) continue;
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      f32x4 ds2[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int t = 2 * sidx + u;
+        f32x4 st = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Kr, KPITCH, t * 16, ks, lane), qf[ks], st, 0, 0, 0);
+          dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Vr, KPITCH, t * 16, ks, lane), dof[ks], dpt, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kl = t * 16 + g * 4 + r, key = k0 + kl;
+          float dsv = 0.f;
+          if (key < Lk && q < Lq) {
+            float x = st[r] * sscale;
+            if constexpr (BIAS == 1) x += brow[key];
+            int ti = 0;
+            if constexpr (BIAS == 2) { ti = coff - kcode[kl]; x += tab[ti]; if (kreg[kl] != qreg) x += -200.f; }
+            const float pr = __expf(x - lq);
+            dsv = pr * (dpt[r] * drop_mult32(dc, (uint32_t)q * (uint32_t)Lk + key) - delta);
+            if constexpr (BIAS == 2) atomicAdd(&dtab[g * ntab + ti], dsv);
+          }
+          ds2[u][r] = dsv;
+        }
+      }
+      const bf16x8 dsf = pack8(ds2[0], ds2[1]);
+      if (dsrow) {
+        const int kb = k0 + sidx * 32;
+        if (kb + g * 4 < Lkp) *reinterpret_cast<bf16x4*>(dsrow + kb + g * 4) = bf16x4{dsf[0], dsf[1], dsf[2], dsf[3]};
+        if (kb + 16 + g * 4 < Lkp) *reinterpret_cast<bf16x4*>(dsrow + kb + 16 + g * 4) = bf16x4{dsf[4], dsf[5], dsf[6], dsf[7]};
+      }
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DKP>(Kt, sidx * 32, dt * 16, lane), dsf, acc[dt], 0, 0, 0);
+    }
+  }
+  if (active && q < Lq) {
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const int d = dt * 16 + g * 4;
+      *reinterpret_cast<bf16x4*>(p.dq + (qrow0 + q) * p.lddq + (long)h * DK + d) =
+          bf16x4{(bf16_t)acc[dt][0], (bf16_t)acc[dt][1], (bf16_t)acc[dt][2], (bf16_t)acc[dt][3]};
+    }
+  }
+  if constexpr (BIAS == 2) {
+    if (p.dbtab_part) {
+      __syncthreads();
+      float* dst = p.dbtab_part + (((long)bt * gridDim.x + blockIdx.x) * p.H + h) * ntab;
+      for (int t = threadIdx.x; t < ntab; t += 256) dst[t] = dtab[t] + dtab[ntab + t] + dtab[2 * ntab + t] + dtab[3 * ntab + t];
+    } else if (p.dbtab) {
+      __syncthreads();
+      for (int t = threadIdx.x; t < ntab; t += 256) {
+        const float v = dtab[t] + dtab[ntab + t] + dtab[2 * ntab + t] + dtab[3 * ntab + t];
+        if (v != 0.f) atomicAdd(p.dbtab + (long)t * p.H + h, v);
+      }
+    }
+  }
+}
+
+// dbtab[t, h] += sum over the partials [nparts, H, ntab] (fixed order: bit-reproducible)
+__global__ __launch_bounds__(256) void dbtab_reduce_kernel(const float* __restrict__ part, long nparts, int H, int ntab, float* __restrict__ dbtab) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)H * ntab) return;
+  const int h = (int)(idx / ntab), t = (int)(idx % ntab);
+  float a = 0.f;
+#pragma unroll 8
+  for (long q = 0; q < nparts; ++q) a += part[(q * H + h) * ntab + t];
+  dbtab[(long)t * H + h] += a;
+}
+
+template <int DK, int BIAS>
+__global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(FlashP p) {
+  constexpr int KS = (DK + 31) / 32, DKP = KS * 32, DT = DK / 16, KPITCH = DKP * 2 + 16, CPR = DKP / 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Qr = smem;
+  char* dOr = Qr + FKB * KPITCH;
+  char* Qt = dOr + FKB * KPITCH;
+  char* dOt = Qt + TrImg<DKP>::bytes(FKB);
+  float* delta = reinterpret_cast<float*>(dOt + TrImg<DKP>::bytes(FKB));
+  float* lses = delta + FKB;
+  int* qcode = reinterpret_cast<int*>(lses + FKB);
+  int* qreg = qcode + FKB;
+  float* tab = reinterpret_cast<float*>(qreg + FKB);
+  const int Lq = p.Lq, Lk = p.Lk;
+  const int bt = blockIdx.y / p.H, h = blockIdx.y % p.H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+  const long qrow0 = (long)bt * Lq, krow0 = (long)bt * Lk;
+  const int kt0 = blockIdx.x * 64 + wave * 16;
+  const bool active = kt0 < Lk;
+  const int key = kt0 + (lane & 15);
+  const int kc = key < Lk ? key : Lk - 1;
+  const int win = BIAS == 2 ? bt % p.nW : 0;
+  int kreg_ = 0, koff = 0;
+  if constexpr (BIAS == 2) {
+    const int ntab = (2 * p.w - 1) * (2 * p.w - 1);
+    for (int t = threadIdx.x; t < ntab; t += 256) tab[t] = p.btab[(long)t * p.H + h];
+    int kcode_;
+    flash_tok(p, win, kc, kcode_, kreg_);
+    koff = 2 * p.w * (p.w - 1) - kcode_;
+  }
+  bf16x8 kf[KS], vf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int c = ks * 32 + g * 8;
+    bf16x8 a = {}, b = {};
+    if (c < DK) {
+      a = *reinterpret_cast<const bf16x8*>(p.k + (krow0 + kc) * p.ldk + (long)h * DK + c);
+      b = *reinterpret_cast<const bf16x8*>(p.v + (krow0 + kc) * p.ldv + (long)h * DK + c);
+    }
+    kf[ks] = a; vf[ks] = b;
+  }
+  const float sscale = p.score_scale ? p.score_scale[h] : 1.f;
+  const float* biasp = nullptr;
+  if constexpr (BIAS == 1) biasp = p.bias + (p.bias_mod > 0 ? (long)(bt % p.bias_mod) * p.H * Lq * Lk : 0L) + (long)h * Lq * Lk;
+  const DropCtx dc = drop_slab(make_drop(p.seed, p.tag, p.p), (uint32_t)(bt * p.H + h));
+  f32x4 av[DT], ak[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) { av[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; ak[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  for (int i0 = 0; i0 < Lq; i0 += FKB) {
+    __syncthreads();
+    // Q, dO of the block into row + transposed images; delta = dO . O and the LSE per row from the same pass
+    for (int ch = threadIdx.x; ch < FKB * CPR; ch += 256) {
+      const int r = ch / CPR, c = (ch % CPR) * 8;
+      bf16x8 vq = {}, vd = {}, vo = {};
+      const bool in = i0 + r < Lq && c < DK;
+      if (in) {
+        vq = *reinterpret_cast<const bf16x8*>(p.q + (qrow0 + i0 + r) * p.ldq + (long)h * DK + c);
+        vd = *reinterpret_cast<const bf16x8*>(p.dout + (qrow0 + i0 + r) * p.lddo + (long)h * DK + c);
+        vo = *reinterpret_cast<const bf16x8*>(p.o + (qrow0 + i0 + r) * p.ldo + (long)h * DK + c);
+      }
+      *reinterpret_cast<bf16x8*>(Qr + r * KPITCH + c * 2) = vq;
+      *reinterpret_cast<bf16x8*>(dOr + r * KPITCH + c * 2) = vd;
+      *reinterpret_cast<bf16x8*>(Qt + TrImg<DKP>::off(r, c)) = vq;
+      *reinterpret_cast<bf16x8*>(dOt + TrImg<DKP>::off(r, c)) = vd;
+      float a = 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += (float)vd[u] * (float)vo[u];
+#pragma unroll
+      for (int o2 = 1; o2 < CPR; o2 <<= 1) a += __shfl_xor(a, o2, 64);  // the CPR lanes of a row are neighbours
+      if (c == 0) {
+        delta[r] = a;
+        lses[r] = i0 + r < Lq ? p.lse[((long)bt * p.H + h) * Lq + i0 + r] : INFINITY;  // padded queries: P = exp(-inf) = 0
+        if constexpr (BIAS == 2) {
+          int cc = 0, rr = -1;
+          if (i0 + r < Lq) flash_tok(p, win, i0 + r, cc, rr);
+          qcode[r] = cc; qreg[r] = rr;
+        }
+      }
+    }
+    __syncthreads();
+    if (!active) continue;
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      f32x4 pd2[2], ds2[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int qt = 2 * sidx + u;
+        f32x4 st = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Qr, KPITCH, qt * 16, ks, lane), kf[ks], st, 0, 0, 0);
+          dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(dOr, KPITCH, qt * 16, ks, lane), vf[ks], dpt, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ql = qt * 16 + g * 4 + r, qq = i0 + ql;
+          float pdv = 0.f, dsv = 0.f;
+          if (key < Lk && qq < Lq) {
+            float x = st[r] * sscale;
+            if constexpr (BIAS == 1) x += biasp[(long)qq * Lk + key];
+            if constexpr (BIAS == 2) { x += tab[qcode[ql] + koff]; if (qreg[ql] != kreg_) x += -200.f; }
+            const float pr = __expf(x - lses[ql]);
+            const float mlt = drop_mult32(dc, (uint32_t)qq * (uint32_t)Lk + key);
+            pdv = pr * mlt;
+            dsv = pr * (dpt[r] * mlt - delta[ql]);
+          }
+          pd2[u][r] = pdv; ds2[u][r] = dsv;
+        }
+      }
+      const bf16x8 pdf = pack8(pd2[0], pd2[1]), dsf = pack8(ds2[0], ds2[1]);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        av[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DKP>(dOt, sidx * 32, dt * 16, lane), pdf, av[dt], 0, 0, 0);
+        ak[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DKP>(Qt, sidx * 32, dt * 16, lane), dsf, ak[dt], 0, 0, 0);
+      }
+    }
+  }
+  if (active && key < Lk) {
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const int d = dt * 16 + g * 4;
+      *reinterpret_cast<bf16x4*>(p.dv + (krow0 + key) * p.lddv + (long)h * DK + d) =
+          bf16x4{(bf16_t)av[dt][0], (bf16_t)av[dt][1], (bf16_t)av[dt][2], (bf16_t)av[dt][3]};
+      *reinterpret_cast<bf16x4*>(p.dkk + (krow0 + key) * p.lddk + (long)h * DK + d) =
+          bf16x4{(bf16_t)ak[dt][0], (bf16_t)ak[dt][1], (bf16_t)ak[dt][2], (bf16_t)ak[dt][3]};
+    }
+  }
+}
+
+template <int DK, int BIAS>
+static int flash_launch(const FlashP& p, int which, hipStream_t s) {
+  constexpr int KS = (DK + 31) / 32, DKP = KS * 32, KPITCH = DKP * 2 + 16;
+  const size_t ntab = BIAS == 2 ? (size_t)(2 * p.w - 1) * (2 * p.w - 1) : 0;
+  const size_t tr = TrImg<DKP>::bytes(FKB);
+  int rc;
+  if (which == 0) {
+    const size_t lds = (size_t)FKB * KPITCH + tr + 2 * FKB * 4 + ntab * 4;
+    rc = ensure_dyn_lds(reinterpret_cast<const void*>(flash_fwd_kernel<DK, BIAS>), lds); if (rc) return rc;
+    hipLaunchKernelGGL((flash_fwd_kernel<DK, BIAS>), dim3((p.Lq + 63) / 64, p.Bt * p.H), dim3(256), lds, s, p);
+  } else if (which == 1) {
+    const size_t lds = 2 * (size_t)FKB * KPITCH + tr + 2 * FKB * 4 + 5 * ntab * 4;
+    rc = ensure_dyn_lds(reinterpret_cast<const void*>(flash_bwd_dq_kernel<DK, BIAS>), lds); if (rc) return rc;
+    hipLaunchKernelGGL((flash_bwd_dq_kernel<DK, BIAS>), dim3((p.Lq + 63) / 64, p.Bt * p.H), dim3(256), lds, s, p);
+  } else {
+    const size_t lds = 2 * (size_t)FKB * KPITCH + 2 * tr + 4 * FKB * 4 + ntab * 4;
+    rc = ensure_dyn_lds(reinterpret_cast<const void*>(flash_bwd_dkv_kernel<DK, BIAS>), lds); if (rc) return rc;
+    hipLaunchKernelGGL((flash_bwd_dkv_kernel<DK, BIAS>), dim3((p.Lk + 63) / 64, p.Bt * p.H), dim3(256), lds, s, p);
+  }
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+
+// which: 0 forward, 1 d q (+ d bias), 2 d k / d v.  dk in {32, 64}; bias_form 0 / 1 / 2
+int flash_attn_dispatch(const FlashP& p, int dk, int bias_form, int which, hipStream_t s) {
+#define FL(D, BF) return flash_launch<D, BF>(p, which, s)
+  if (dk == 32) { if (bias_form == 0) FL(32, 0); if (bias_form == 1) FL(32, 1); if (bias_form == 2) FL(32, 2); }
+  if (dk == 64) { if (bias_form == 0) FL(64, 0); if (bias_form == 1) FL(64, 1); if (bias_form == 2) FL(64, 2); }
+#undef FL
+  return KLAB_ERR_UNSUPPORTED;
+}
+
 template <typename K>
 static int set_lds_attr(K kern, size_t bytes) { return ensure_dyn_lds(reinterpret_cast<const void*>(kern), bytes); }
 
@@ -518,32 +1008,92 @@ static AttnMP to_mp(const klab_attn_args* a) {
   return p;
 }
 
+static int t5_flash_fallback_fwd(const AttnMP& p, int dk, hipStream_t s);
 // returns KLAB_ERR_UNSUPPORTED when the shape is outside this kernel's envelope (caller falls back)
 int t5_attn_fwd_mfma_dispatch(const klab_attn_args* a, hipStream_t s) {
   if (a->dtype != KLAB_BF16 || (a->ldo & 3) || (a->ldq & 7) || (a->ldk & 7) || (a->ldv & 7)) return KLAB_ERR_UNSUPPORTED;
   AttnMP p = to_mp(a);
+  int rc = KLAB_ERR_UNSUPPORTED;
   switch (a->dk) {
-    case 16: return launch_fwd<16>(p, s);
-    case 32: return launch_fwd<32>(p, s);
-    case 64: return launch_fwd<64>(p, s);
-    case 128: return launch_fwd<128>(p, s);
+    case 16: rc = launch_fwd<16>(p, s); break;
+    case 32: rc = launch_fwd<32>(p, s); break;
+    case 64: rc = launch_fwd<64>(p, s); break;
+    case 128: rc = launch_fwd<128>(p, s); break;
   }
-  return KLAB_ERR_UNSUPPORTED;
+  if (rc == KLAB_ERR_UNSUPPORTED) rc = t5_flash_fallback_fwd(p, a->dk, s);
+  return rc;
 }
+static FlashP to_flash(const AttnMP& p) {
+  FlashP f;
+  memset(&f, 0, sizeof(f));
+  f.q = p.q; f.ldq = p.ldq; f.k = p.k; f.ldk = p.ldk; f.v = p.v; f.ldv = p.ldv; f.o = p.ctx; f.ldo = p.ldo; f.lse = p.lse;
+  f.Bt = p.B; f.H = p.H; f.Lq = p.Lq; f.Lk = p.Lk; f.score_scale = p.score_scale; f.bias = p.bias; f.bias_mod = p.bias_mod;
+  f.p = p.p; f.seed = p.seed; f.tag = p.tag; f.dout = p.dctx; f.lddo = p.lddo;
+  f.dq = p.dq; f.lddq = p.lddq; f.dkk = p.dkk; f.lddk = p.lddk; f.dv = p.dv; f.lddv = p.lddv; f.ds_ws = p.ds_ws;
+  return f;
+}
+// sequences too long for the one-workgroup kernels (T5-large encoder, Le = 153 at head dim 64): the streaming forms
+static int t5_flash_fallback(const AttnMP& p, int dk, bool backward, hipStream_t s) {
+  static const bool on = [] { const char* e = getenv("KLAB_ATTN_FLASH"); return !e || atoi(e) != 0; }();
+  if (!on || p.causal || (dk != 32 && dk != 64)) return KLAB_ERR_UNSUPPORTED;
+  if (backward && p.dbias && !p.ds_ws) return KLAB_ERR_UNSUPPORTED;  // d bias only through the dS scratch
+  const FlashP f = to_flash(p);
+  const int bf = p.bias ? 1 : 0;
+  if (!backward) return flash_attn_dispatch(f, dk, bf, 0, s);
+  int rc = flash_attn_dispatch(f, dk, bf, 1, s);
+  if (rc) return rc;
+  rc = flash_attn_dispatch(f, dk, bf, 2, s);
+  if (rc) return rc;
+  if (p.dbias && p.ds_ws && !p.defer_reduce) {
+    const int Lkp = (p.Lk + 31) & ~31;
+    const long tot = (long)p.H * p.Lq * p.Lk;
+    hipLaunchKernelGGL(dbias_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, p.ds_ws, p.dbias, p.B, p.H * p.Lq, p.Lk, Lkp);
+    KLAB_LAUNCH_CHECK();
+  }
+  return KLAB_OK;
+}
+
 int t5_attn_bwd_mfma_dispatch(const klab_attn_args* a, hipStream_t s) {
   if (a->dtype != KLAB_BF16 || (a->ldo & 7) || (a->ldq & 7) || (a->ldk & 7) || (a->ldv & 7) || (a->lddo & 7) || (a->lddq & 3) ||
       (a->lddk & 3) || (a->lddv & 3))
     return KLAB_ERR_UNSUPPORTED;
   AttnMP p = to_mp(a);
+  int rc = KLAB_ERR_UNSUPPORTED;
   switch (a->dk) {
-    case 16: return launch_bwd<16>(p, s);
-    case 32: return launch_bwd<32>(p, s);
-    case 64: return launch_bwd<64>(p, s);
-    case 128: return launch_bwd<128>(p, s);
+    case 16: rc = launch_bwd<16>(p, s); break;
+    case 32: rc = launch_bwd<32>(p, s); break;
+    case 64: rc = launch_bwd<64>(p, s); break;
+    case 128: rc = launch_bwd<128>(p, s); break;
   }
-  return KLAB_ERR_UNSUPPORTED;
+  if (rc == KLAB_ERR_UNSUPPORTED) rc = t5_flash_fallback(p, a->dk, true, s);
+  return rc;
 }
 
+
+static int t5_flash_fallback_fwd(const AttnMP& p, int dk, hipStream_t s) { return t5_flash_fallback(p, dk, false, s); }
+
+// Swin-V2 large windows on window-major copies (attn_swin.hip): see FlashP
+int swin_flash_dispatch(const void* g, long ldg, int C, void* otok, long ldot, float* lse, int Bt, int H, int n, const float* scale,
+                        const float* btab, float* dbtab, float* dbtab_part, int w, int R, int shift, int nW, const void* ow,
+                        const void* dow, void* dg, int which, hipStream_t s) {
+  FlashP f;
+  memset(&f, 0, sizeof(f));
+  const bf16_t* gb = (const bf16_t*)g;
+  f.q = gb; f.k = gb + C; f.v = gb + 2 * C; f.ldq = f.ldk = f.ldv = ldg;
+  f.o = (bf16_t*)ow; f.ldo = C; f.otok = (bf16_t*)otok; f.ldot = ldot; f.lse = lse;
+  f.Bt = Bt; f.H = H; f.Lq = f.Lk = n; f.score_scale = scale; f.btab = btab; f.dbtab = dbtab; f.w = w; f.R = R; f.shift = shift; f.nW = nW;
+  f.dout = (const bf16_t*)dow; f.lddo = C;
+  bf16_t* dgb = (bf16_t*)dg;
+  f.dq = dgb; f.dkk = dgb ? dgb + C : nullptr; f.dv = dgb ? dgb + 2 * C : nullptr; f.lddq = f.lddk = f.lddv = ldg;
+  f.dbtab_part = (which == 1 && dbtab) ? dbtab_part : nullptr;
+  const int rc = flash_attn_dispatch(f, 32, 2, which, s);
+  if (rc || !f.dbtab_part) return rc;
+  const int ntab = (2 * w - 1) * (2 * w - 1);
+  hipLaunchKernelGGL(dbtab_reduce_kernel, dim3((unsigned)(((long)H * ntab + 255) / 256)), dim3(256), 0, s, f.dbtab_part,
+                     (long)Bt * ((n + 63) / 64), H, ntab, dbtab);
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
 
 int dbias_reduce_dispatch(const void* ds_ws, float* dbias, int nbatch, int H, int Lq, int Lk, hipStream_t s) {
   const int Lkp = (Lk + 31) & ~31;

@@ -570,12 +570,16 @@ size_t plan_workspace(klab_engine* e, void* base, int B, int Ls, int Lt) {
     e->sdbias = (float*)b.take((size_t)maxH * maxn_small * maxn_small * 4);  // dense d(bias) of the one-tile windows
     e->sdbtab = (float*)b.take((size_t)(4 * maxn) * maxH * 4);               // d(bias table) of the large windows
     e->sdtable = (float*)b.take((size_t)(4 * maxn) * maxH * 4 + (size_t)(4 * maxn) * 512 * 4);
+  }
+  {  // scratch of the matrix-core window attention: backward of the one-tile windows (train_swin), and forward + backward of
+     // windows of more than 64 tokens (window-major copies for the streaming kernels)
     e->sattn_ws = nullptr; e->sattn_ws_bytes = 0;
-    const char* ev = getenv("KLAB_SWIN_BWD_MFMA");  // "0": keep the vector-ALU window-attention backward (A/B switch)
+    const char* ev = getenv("KLAB_SWIN_BWD_MFMA");  // "0": keep the vector-ALU window-attention kernels (A/B switch)
     if (!(ev && ev[0] == '0')) {
       size_t need = 0;
       for (int st = 0; st < s.n_stages; ++st) {
         const int R = R0 >> st; const int w = R < s.window ? R : s.window;
+        if (!c.train_swin && w * w <= 64) continue;  // frozen tower, one-tile window: the forward kernels need no scratch
         const size_t x = klab_swin_attn_bwd_ws_bytes(c.dtype, B, R, w, s.heads[st], s.embed_dim << st);
         if (x > need) need = x;  // (0: that stage is outside the matrix-core envelope and runs its own kernels)
       }
@@ -945,6 +949,7 @@ int swin_forward(const Ctx& c, const float* pixels, float p_in, bool refresh_bia
         memset(&a, 0, sizeof(a));
         a.dtype = c.dt; a.qkv = q.qkv; a.ctx = q.ctx; a.bias = q.bias; a.bias_table = q.btab; a.logit_scale = W[ix.ls]; a.lse = q.lse;
         a.B = B; a.R = q.R; a.w = q.w; a.shift = q.shift; a.H = q.H; a.C = C;
+        a.bwd_ws = e->sattn_ws; a.bwd_ws_bytes = e->sattn_ws_bytes;  // (large windows: window-major copies for the streaming kernel)
         RC(klab_swin_attn_fwd(&a, c.ws()));
       }
       static const bool fused_proj = [] { const char* v = getenv("KLAB_SWIN_FUSED_PROJ"); return !v || atoi(v) != 0; }();

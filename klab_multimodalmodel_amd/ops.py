@@ -179,10 +179,17 @@ def _swin_args(qkv, ctx, bias, logit_scale, lse, B, R, w, shift, H, Cc, bias_tab
     return a
 
 
-def swin_attn_fwd(qkv, ctx, bias, logit_scale, lse=None, *, B, R, w, shift, H, C, bias_table=None):
-    """bias [H, n, n] dense, or bias=None + bias_table [(2w-1)^2, H] (large windows: looked up per score)"""
+def swin_attn_fwd(qkv, ctx, bias, logit_scale, lse=None, *, B, R, w, shift, H, C, bias_table=None, mfma=True):
+    """bias [H, n, n] dense, or bias=None + bias_table [(2w-1)^2, H] (large windows: looked up per score); mfma=True hands the
+    kernel the scratch its matrix-core form needs for windows of more than 64 tokens (False: the vector-ALU tiled kernel)"""
+    import torch
     lib = L.load()
     a = _swin_args(qkv, ctx, bias, logit_scale, lse, B, R, w, shift, H, C, bias_table)
+    if mfma and w * w > 64:
+        nbytes = lib.klab_swin_attn_bwd_ws_bytes(a.dtype, B, R, w, H, C)
+        if nbytes:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=qkv.device)
+            a.bwd_ws, a.bwd_ws_bytes = ws.data_ptr(), nbytes
     L.check(lib.klab_swin_attn_fwd(C_byref(a), L.stream_ptr()), "klab_swin_attn_fwd")
 
 

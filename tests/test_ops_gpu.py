@@ -275,6 +275,70 @@ def test_t5_attention_fwd_bwd(ops, dt, B, H, Lq, Lk, dk, causal, use_bias):
         assert rel_l2(dbias.cpu(), bref.grad) < t
 
 
+@pytest.mark.parametrize("B,H,Lq,Lk,dk,use_bias", [(2, 16, 153, 153, 64, True), (1, 2, 300, 300, 32, True), (2, 3, 200, 90, 64, False)])
+def test_t5_attention_long_sequences_streaming_kernels(ops, B, H, Lq, Lk, dk, use_bias):
+    """sequences whose Q / K / V / dO images exceed one workgroup's LDS (T5-large encoder: Le = 153 at head dim 64, BASELINE
+    configs[4]) run the streaming matrix-core kernels (flash_fwd / flash_bwd_dq / flash_bwd_dkv): forward, d q / d k / d v and
+    the position-bias gradient (stored-dS form) against the fp32 reference."""
+    dt = torch.bfloat16
+    inner = H * dk
+    qb, kb, vb = (rnd(B * L_, inner, seed=sd_, scale=0.5).to(dt) for L_, sd_ in ((Lq, 1), (Lk, 2), (Lk, 3)))
+    bias = rnd(H, Lq, Lk, seed=4) if use_bias else None
+    dctx = rnd(B * Lq, inner, seed=5).to(dt)
+    q = qb.float().view(B, Lq, H, dk).transpose(1, 2).clone().requires_grad_(True)
+    k = kb.float().view(B, Lk, H, dk).transpose(1, 2).clone().requires_grad_(True)
+    v = vb.float().view(B, Lk, H, dk).transpose(1, 2).clone().requires_grad_(True)
+    bref = bias.clone().requires_grad_(True) if use_bias else None
+    ref = _attn_ref(q, k, v, bref, False)
+    ref.backward(dctx.float().view(B, Lq, H, dk).transpose(1, 2))
+    ctx = torch.zeros(B * Lq, inner, device="cuda", dtype=dt)
+    lse = torch.empty(B, H, Lq, device="cuda")
+    kw = dict(B=B, H=H, Lq=Lq, Lk=Lk, dk=dk, bias=dev(bias) if use_bias else None, causal=False)
+    qd, kd, vd = dev(qb), dev(kb), dev(vb)
+    ops.t5_attn_fwd(qd, kd, vd, ctx, lse, **kw)
+    assert rel_l2(ctx.float().cpu(), ref.detach().transpose(1, 2).reshape(B * Lq, inner)) < tol(dt)
+    dq, dk_, dv = (torch.zeros(B * L_, inner, device="cuda", dtype=dt) for L_ in (Lq, Lk, Lk))
+    dbias = torch.zeros(H, Lq, Lk, device="cuda") if use_bias else None
+    ds_ws = torch.empty(B * H * Lq * ((Lk + 31) // 32 * 32), device="cuda", dtype=dt) if use_bias else None
+    ops.t5_attn_bwd(qd, kd, vd, ctx, lse, dev(dctx), dq, dk_, dv, dbias=dbias, ds_ws=ds_ws, **kw)
+    t = tol(dt) * 2
+    assert rel_l2(dq.float().cpu(), q.grad.transpose(1, 2).reshape(B * Lq, inner)) < t
+    assert rel_l2(dk_.float().cpu(), k.grad.transpose(1, 2).reshape(B * Lk, inner)) < t
+    assert rel_l2(dv.float().cpu(), v.grad.transpose(1, 2).reshape(B * Lk, inner)) < t
+    if use_bias:
+        assert rel_l2(dbias.cpu(), bref.grad) < t
+    # dropout: the mask is a pure function of (seed, tag, b, h, q, key).  Read it out through the kernel itself -- Q = K = 0 gives
+    # uniform probabilities 1/Lk, V = one-hot over a chunk of dk keys, so ctx[q, d] = multiplier(q, c0 + d) / Lk -- then check
+    # forward AND backward against the reference with exactly that mask.
+    sd = seed_word(5)
+    pdrop = 0.25
+    kwd = dict(B=B, H=H, Lq=Lq, Lk=Lk, dk=dk, drop_p=pdrop, seed=sd, tag=9)
+    mask = torch.zeros(B, H, Lq, Lk)
+    zq, zk = torch.zeros_like(qd), torch.zeros_like(kd)
+    for c0 in range(0, Lk, dk):
+        onehot = torch.zeros(B, Lk, H, dk)
+        for d in range(min(dk, Lk - c0)):
+            onehot[:, c0 + d, :, d] = 1.0
+        cc = torch.empty_like(ctx)
+        ops.t5_attn_fwd(zq, zk, dev(onehot.reshape(B * Lk, inner).to(dt)), cc, lse, **kwd)
+        got = cc.float().cpu().view(B, Lq, H, dk).permute(0, 2, 1, 3) * Lk
+        mask[:, :, :, c0:c0 + dk] = got[..., :min(dk, Lk - c0)]
+    keep = (mask > 0.5).float()
+    assert abs(float(keep.mean()) - (1 - pdrop)) < 0.02 and float((mask * keep).max()) < 1.0 / (1 - pdrop) * 1.02
+    q2, k2, v2 = (x.detach().clone().requires_grad_(True) for x in (q, k, v))
+    sc = q2 @ k2.transpose(-1, -2) + (bias if use_bias else 0.0)
+    ref2 = (torch.softmax(sc, -1) * keep / (1 - pdrop)) @ v2
+    ref2.backward(dctx.float().view(B, Lq, H, dk).transpose(1, 2))
+    c1 = torch.empty_like(ctx)
+    kwd2 = dict(kwd, bias=dev(bias) if use_bias else None)
+    ops.t5_attn_fwd(qd, kd, vd, c1, lse, **kwd2)
+    assert rel_l2(c1.float().cpu(), ref2.detach().transpose(1, 2).reshape(B * Lq, inner)) < tol(dt)
+    ops.t5_attn_bwd(qd, kd, vd, c1, lse, dev(dctx), dq, dk_, dv, **kwd2)
+    assert rel_l2(dq.float().cpu(), q2.grad.transpose(1, 2).reshape(B * Lq, inner)) < t
+    assert rel_l2(dk_.float().cpu(), k2.grad.transpose(1, 2).reshape(B * Lk, inner)) < t
+    assert rel_l2(dv.float().cpu(), v2.grad.transpose(1, 2).reshape(B * Lk, inner)) < t
+
+
 def test_t5_attention_dropout_fwd_bwd_consistent(ops):
     # with dropout on, backward must regenerate the forward's mask: check d(ctx)/dV numerically via linearity in V
     B, H, L, dk, p = 2, 2, 24, 16, 0.3
@@ -416,16 +480,18 @@ def test_swin_large_window_attention_fwd_bwd(ops, dt, B, R, w, shift, H, C):
     nW = (R // w) ** 2
     kw = dict(B=B, R=R, w=w, shift=shift, H=H, C=C)
     t = tol(dt) * 4
-    for form in ("table", "dense"):
+    forms = ("table", "dense") + (("table-valu",) if dt == torch.bfloat16 and C == H * 32 else ())
+    for form in forms:  # bf16 "table" = the matrix-core streaming kernels, "table-valu" = the vector-ALU tiled kernels
         ctx = torch.empty(B * R * R, C, device="cuda", dtype=dt)
         lse = torch.empty(B * nW * H * n, device="cuda")
         dqkv = torch.empty(B * R * R, 3 * C, device="cuda", dtype=dt)
         dls = torch.zeros(H, device="cuda")
-        if form == "table":
+        if form.startswith("table"):
             dtab = torch.zeros(ntab, H, device="cuda")
-            ops.swin_attn_fwd(dev(qkv), ctx, None, dev(ls), lse, bias_table=dev(btab), **kw)
-            ops.swin_attn_bwd(dev(qkv), ctx, None, dev(ls), lse, dev(dctx), dqkv, None, dls, bias_table=dev(btab), dbias_table=dtab, **kw)
-            assert rel_l2(dtab.cpu(), tr.grad) < t
+            mf = form == "table"
+            ops.swin_attn_fwd(dev(qkv), ctx, None, dev(ls), lse, bias_table=dev(btab), mfma=mf, **kw)
+            ops.swin_attn_bwd(dev(qkv), ctx, None, dev(ls), lse, dev(dctx), dqkv, None, dls, bias_table=dev(btab), dbias_table=dtab, mfma=mf, **kw)
+            assert rel_l2(dtab.cpu(), tr.grad) < t, form
         else:
             bd = _table_to_dense(btab, index, H, n)
             dbias = torch.zeros(H, n, n, device="cuda")
