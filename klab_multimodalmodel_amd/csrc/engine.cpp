@@ -142,6 +142,10 @@ struct klab_engine {
   float *sdh_a = nullptr, *sdh_b = nullptr, *sdm = nullptr; void *sdy = nullptr, *sdctx = nullptr, *sdqkv = nullptr, *sda = nullptr;
   void* sattn_ws = nullptr; size_t sattn_ws_bytes = 0;
   float *sdbias = nullptr, *sdtable = nullptr, *sdbtab = nullptr;
+  // Swin weight gradients on the side stream: per-block gradient operands in two alternating sets (block k+2 reuses set k & 1
+  // once swin_done_ev[k & 1] -- recorded on the side stream behind block k's weight gradients -- has fired)
+  void *sdyA[2] = {nullptr, nullptr}, *sdyB[2] = {nullptr, nullptr}, *sdaP[2] = {nullptr, nullptr}, *sdqkvP[2] = {nullptr, nullptr};
+  hipEvent_t swin_done_ev[2] = {nullptr, nullptr};
   // side stream: independent chains run beside the main one (frozen language encoder || Swin; weight gradients ||
   // the activation-gradient chain); joined back with events before anything the caller can observe
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -560,6 +564,10 @@ size_t plan_workspace(klab_engine* e, void* base, int B, int Ls, int Lt) {
     e->sdm = (float*)b.take((size_t)maxMC * 4);
     e->sdy = b.take((size_t)maxMC * es); e->sdctx = b.take((size_t)maxMC * es);
     e->sdqkv = b.take((size_t)maxMC * 3 * es); e->sda = b.take((size_t)maxMC * F0 * es);
+    for (int pz = 0; pz < 2; ++pz) {
+      e->sdyA[pz] = b.take((size_t)maxMC * es); e->sdyB[pz] = b.take((size_t)maxMC * es);
+      e->sdaP[pz] = b.take((size_t)maxMC * F0 * es); e->sdqkvP[pz] = b.take((size_t)maxMC * 3 * es);
+    }
     int maxn = 0, maxH = 0, maxn_small = 1;
     for (int st = 0; st < s.n_stages; ++st) {
       const int R = R0 >> st; const int w = R < s.window ? R : s.window;
@@ -1043,6 +1051,7 @@ extern "C" void klab_engine_destroy(klab_engine* e) {
   if (e->ev_out) hipEventDestroy(e->ev_out);
   for (auto ev : e->evpool) if (ev) hipEventDestroy(ev);
   for (auto& v : e->bucket_ev) for (auto ev : v) if (ev) hipEventDestroy(ev);
+  for (auto ev : e->swin_done_ev) if (ev) hipEventDestroy(ev);
   for (auto& pr : e->probe) {
     for (auto ev : pr.a) if (ev) hipEventDestroy(ev);
     for (auto ev : pr.b) if (ev) hipEventDestroy(ev);
@@ -1271,6 +1280,7 @@ extern "C" int klab_engine_bind(klab_engine* e, int B, int Ls, int Lt, void* wor
     for (auto& ev : e->evpool) RC((int)hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     RC((int)hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
     RC((int)hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming));
+    for (auto& ev : e->swin_done_ev) RC((int)hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     for (int sg = 0; sg < 3; ++sg) {
       e->bucket_ev[sg].assign(e->buckets[sg].size(), nullptr);
       for (auto& ev : e->bucket_ev[sg]) RC((int)hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -1696,7 +1706,10 @@ int swin_backward(const Ctx& c, const float* dh0, float p_in) {
   for (int st = 0; st < s.n_stages; ++st) bias_off_total += 3L * (C0 << st) * s.depths[st];
   long bias_off = bias_off_total;
   (void)bias_off;
-  int swin_bucket = 0;
+  int swin_bucket = 0, blk_no = 0;
+  static const bool side_env = [] { const char* v = getenv("KLAB_SWIN_SIDE_WGRAD"); return !v || atoi(v) != 0; }();
+  const bool side_on = side_env && e->sdyA[0] != nullptr;
+  const Ctx cs{e, e->side, c.dt, c.es};
   for (int st = last; st >= 0; --st) {
     SwinStageBufs& sb = e->sw[st];
     const int R = R0 >> st, C = C0 << st;
@@ -1714,32 +1727,49 @@ int swin_backward(const Ctx& c, const float* dh0, float p_in) {
       SwinBlockBufs& q = sb.blk[k];
       const SwinBlockIdx& ix = e->si.st[st].blk[k];
       const int M = (int)q.M, F = s.mlp_ratio * C, n = q.w * q.w;
+      // The activation-gradient chain (LayerNorm', dgrad GEMMs, attention backward) stays on the main stream; the block's
+      // bias column sums and weight-gradient GEMMs trail on the side stream (as the T5 stacks do).  Their operands live in
+      // one of two alternating buffer sets: before the main stream rewrites a set it waits for the side stream's event of the
+      // block that used it last.
+      const int par = blk_no & 1;
+      if (side_on && blk_no >= 2) RC((int)hipStreamWaitEvent(c.s, e->swin_done_ev[par], 0));
+      void* dyA = side_on ? e->sdyA[par] : e->sdy;     // d fo   (LayerNorm-after backward)
+      void* dyB = side_on ? e->sdyB[par] : e->sdy;     // d po   (LayerNorm-before backward)
+      void* da = side_on ? e->sdaP[par] : e->sda;      // d z
+      void* dqkv = side_on ? e->sdqkvP[par] : e->sdqkv;
+      const Ctx& cw = side_on ? cs : c;                // where the weight gradients go
       // h2 = h1 + LN2(fo):  d fo = LN2'(dh);  dh flows through the shortcut unchanged
-      RC(klab_layernorm_bwd(dh, q.fo, c.dt, W[ix.ln2w], q.mean2, q.rstd2, e->sdy, G(ix.ln2w), G(ix.ln2b), M, C, 0, 0, 0, 0.f, nullptr, 0, c.ws()));
-      RC(klab_colsum(e->sdy, C, c.dt, M, C, G(ix.f2b), c.ws()));
-      RC(linear_wgrad(c, e->sdy, C, q.a, F, M, C, F, G(ix.f2w)));
+      RC(klab_layernorm_bwd(dh, q.fo, c.dt, W[ix.ln2w], q.mean2, q.rstd2, dyA, G(ix.ln2w), G(ix.ln2b), M, C, 0, 0, 0, 0.f, nullptr, 0, c.ws()));
+      if (!side_on) {
+        RC(klab_colsum(dyA, C, c.dt, M, C, G(ix.f2b), c.ws()));
+        RC(linear_wgrad(c, dyA, C, q.a, F, M, C, F, G(ix.f2w)));
+      }
       {  // d z = (d fo @ W2) * gelu'(z)
-        klab_gemm_args g = G0(c, M, F, C, e->sdy, C, 1, woff(c, P[ix.f2w].warena_off), F, 0, e->sda, F, c.dt);
+        klab_gemm_args g = G0(c, M, F, C, dyA, C, 1, woff(c, P[ix.f2w].warena_off), F, 0, da, F, c.dt);
         g.aux = q.z; g.ldaux = F; g.aux_mode = KLAB_AUX_DGELU;
         RC(klab_gemm(&g, c.ws()));
       }
-      RC(klab_colsum(e->sda, F, c.dt, M, F, G(ix.f1b), c.ws()));
-      RC(linear_wgrad(c, e->sda, F, q.h1t, C, M, F, C, G(ix.f1w)));
+      if (!side_on) {
+        RC(klab_colsum(da, F, c.dt, M, F, G(ix.f1b), c.ws()));
+        RC(linear_wgrad(c, da, F, q.h1t, C, M, F, C, G(ix.f1w)));
+      }
       {  // dh1 = dh + d z @ W1   (accumulate into the stream gradient)
-        klab_gemm_args g = G0(c, M, C, F, e->sda, F, 1, woff(c, P[ix.f1w].warena_off), C, 0, dh, C, KLAB_F32);
+        klab_gemm_args g = G0(c, M, C, F, da, F, 1, woff(c, P[ix.f1w].warena_off), C, 0, dh, C, KLAB_F32);
         g.accumulate = 1;
         RC(klab_gemm(&g, c.ws()));
       }
       // h1 = x + LN1(po)
-      RC(klab_layernorm_bwd(dh, q.po, c.dt, W[ix.ln1w], q.mean1, q.rstd1, e->sdy, G(ix.ln1w), G(ix.ln1b), M, C, 0, 0, 0, 0.f, nullptr, 0, c.ws()));
-      RC(klab_colsum(e->sdy, C, c.dt, M, C, G(ix.pb), c.ws()));
-      RC(linear_wgrad(c, e->sdy, C, q.ctx, C, M, C, C, G(ix.pw)));
-      RC(linear_dgrad(c, e->sdy, C, M, C, P[ix.pw].warena_off, C, e->sdctx, c.dt));
+      RC(klab_layernorm_bwd(dh, q.po, c.dt, W[ix.ln1w], q.mean1, q.rstd1, dyB, G(ix.ln1w), G(ix.ln1b), M, C, 0, 0, 0, 0.f, nullptr, 0, c.ws()));
+      if (!side_on) {
+        RC(klab_colsum(dyB, C, c.dt, M, C, G(ix.pb), c.ws()));
+        RC(linear_wgrad(c, dyB, C, q.ctx, C, M, C, C, G(ix.pw)));
+      }
+      RC(linear_dgrad(c, dyB, C, M, C, P[ix.pw].warena_off, C, e->sdctx, c.dt));
       klab_swin_attn_args a;
       memset(&a, 0, sizeof(a));
       a.dtype = c.dt; a.qkv = q.qkv; a.ctx = q.ctx; a.bias = q.bias; a.bias_table = q.btab; a.logit_scale = W[ix.ls]; a.lse = q.lse;
       a.B = B; a.R = q.R; a.w = q.w; a.shift = q.shift; a.H = q.H; a.C = C;
-      a.dctx = e->sdctx; a.dqkv = e->sdqkv; a.dlogit_scale = G(ix.ls);
+      a.dctx = e->sdctx; a.dqkv = dqkv; a.dlogit_scale = G(ix.ls);
       a.bwd_ws = e->sattn_ws; a.bwd_ws_bytes = e->sattn_ws_bytes;
       if (q.btab) {  // large window: the bias gradient is accumulated per table entry
         RC((int)hipMemsetAsync(e->sdbtab, 0, (size_t)e->swin_ntab[st] * q.H * 4, c.s));
@@ -1754,21 +1784,43 @@ int swin_backward(const Ctx& c, const float* dh0, float p_in) {
         RC(klab_swin_cpb_bias_bwd(e->sdbias, q.bias, e->swin_index[st], e->swin_coords[st], q.hidden, W[ix.c0w], W[ix.c2w], e->sdtable,
                                   G(ix.c0w), G(ix.c0b), G(ix.c2w), e->swin_ntab[st], n, q.H, 512, c.ws()));
       }
-      if (ix.qb >= 0) {
-        RC(klab_colsum(e->sdqkv, 3 * C, c.dt, M, C, G(ix.qb), c.ws()));
-        RC(klab_colsum((char*)e->sdqkv + (size_t)2 * C * c.es, 3 * C, c.dt, M, C, G(ix.vb), c.ws()));
+      if (side_on) {  // everything the block's weight gradients read exists now: release them to the side stream
+        RC(side_after_main(c));
+        RC(klab_colsum(dyA, C, c.dt, M, C, G(ix.f2b), cw.ws()));
+        RC(klab_colsum(da, F, c.dt, M, F, G(ix.f1b), cw.ws()));
+        RC(klab_colsum(dyB, C, c.dt, M, C, G(ix.pb), cw.ws()));
       }
-      RC(linear_wgrad(c, e->sdqkv, 3 * C, q.xt_in, C, M, 3 * C, C, G(ix.qw)));  // q|k|v grads adjacent
+      if (ix.qb >= 0) {
+        RC(klab_colsum(dqkv, 3 * C, c.dt, M, C, G(ix.qb), cw.ws()));
+        RC(klab_colsum((char*)dqkv + (size_t)2 * C * c.es, 3 * C, c.dt, M, C, G(ix.vb), cw.ws()));
+      }
+      if (side_on) {  // the block's four weight gradients in ONE grouped launch (members outside its form run one by one)
+        klab_gemm_args gs[4];
+        auto wg = [&](int i, const void* dy, long lddy, const void* x, long ldx, int N, int K, float* dw) {
+          gs[i] = G0(cw, N, K, M, dy, lddy, 0, x, ldx, 0, dw, K, KLAB_F32);  // as linear_wgrad
+          gs[i].accumulate = 1; gs[i].atomic_ok = 1;
+        };
+        wg(0, dyA, C, q.a, F, C, F, G(ix.f2w));
+        wg(1, da, F, q.h1t, C, F, C, G(ix.f1w));
+        wg(2, dyB, C, q.ctx, C, C, C, G(ix.pw));
+        wg(3, dqkv, 3 * C, q.xt_in, C, 3 * C, C, G(ix.qw));  // q|k|v grads adjacent
+        RC(klab_gemm_grouped(gs, 4, cw.ws()));
+      } else {
+        RC(linear_wgrad(cw, dqkv, 3 * C, q.xt_in, C, M, 3 * C, C, G(ix.qw)));  // q|k|v grads adjacent
+      }
       if (!e->use_graph && swin_bucket < (int)e->bucket_ev[2].size())  // this block's GEMM-weight gradients are final
-        RC((int)hipEventRecord(e->bucket_ev[2][swin_bucket], c.s));
+        RC((int)hipEventRecord(e->bucket_ev[2][swin_bucket], cw.s));
       ++swin_bucket;
+      if (side_on) RC((int)hipEventRecord(e->swin_done_ev[par], cs.s));
+      ++blk_no;
       {
-        klab_gemm_args g = G0(c, M, C, 3 * C, e->sdqkv, 3 * C, 1, woff(c, P[ix.qw].warena_off), C, 0, dh, C, KLAB_F32);
+        klab_gemm_args g = G0(c, M, C, 3 * C, dqkv, 3 * C, 1, woff(c, P[ix.qw].warena_off), C, 0, dh, C, KLAB_F32);
         g.accumulate = 1;
         RC(klab_gemm(&g, c.ws()));
       }
     }
   }
+  if (side_on) RC(main_after_side(c));  // every weight gradient of the tower is behind this point of the caller's stream
   // patch embedding: LN -> conv-as-GEMM (weights + bias only; pixels need no gradient)
   const long M0 = (long)B * R0 * R0;
   const int K0 = s.in_ch * s.patch * s.patch;
