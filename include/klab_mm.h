@@ -297,6 +297,9 @@ long klab_engine_grad_elems(const klab_engine* e, int model);
 int klab_engine_num_buckets(const klab_engine* e, int segment);
 int klab_engine_bucket(const klab_engine* e, int segment, int i, long* off, long* len);
 int klab_engine_bucket_wait(klab_engine* e, int segment, int i, void* stream);
+/* the per-bucket events are recorded only after klab_engine_set_bucket_events(e, 1) (a data-parallel reducer is attached);
+ * off by default: a single-GPU step pays nothing for them                                                            */
+int klab_engine_set_bucket_events(klab_engine* e, int on);
 int klab_engine_segment(const klab_engine* e, int seg, int* model, long* off, long* len);
 size_t klab_engine_workspace_bytes(klab_engine* e, int B, int Ls, int Lt);
 /* *_params: host arrays of device pointers in klab_engine_param_info order.  *_bucket: int32 device

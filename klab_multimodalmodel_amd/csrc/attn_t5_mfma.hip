@@ -700,6 +700,7 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(FlashP p) {
   delta += __shfl_xor(delta, 32, 64);
   const float lq = p.lse[((long)bt * p.H + h) * Lq + qc];
   const float sscale = p.score_scale ? p.score_scale[h] : 1.f;
+  const bool want_dtab = p.dbtab_part != nullptr || p.dbtab != nullptr;
   const float* brow = nullptr;
   if constexpr (BIAS == 1) brow = p.bias + (p.bias_mod > 0 ? (long)(bt % p.bias_mod) * p.H * Lq * Lk : 0L) + ((long)h * Lq + qc) * Lk;
   bf16_t* dsrow = (BIAS == 1 && p.ds_ws && q < Lq) ? p.ds_ws + (((long)bt * p.H + h) * Lq + q) * Lkp : nullptr;
@@ -745,7 +746,7 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(FlashP p) {
             if constexpr (BIAS == 2) { ti = coff - kcode[kl]; x += tab[ti]; if (kreg[kl] != qreg) x += -200.f; }
             const float pr = __expf(x - lq);
             dsv = pr * (dpt[r] * drop_mult32(dc, (uint32_t)q * (uint32_t)Lk + key) - delta);
-            if constexpr (BIAS == 2) atomicAdd(&dtab[g * ntab + ti], dsv);
+            if constexpr (BIAS == 2) { if (want_dtab) atomicAdd(&dtab[g * ntab + ti], dsv); }
           }
           ds2[u][r] = dsv;
         }

@@ -97,7 +97,8 @@ struct klab_engine {
   struct Bucket { long off, len; };
   std::vector<Bucket> buckets[3];
   std::vector<hipEvent_t> bucket_ev[3];
-  bool bucket_ev_live[3] = {false, false, false};  // recorded by the last backward of that segment (never under graph replay)
+  bool bucket_ev_live[3] = {false, false, false};
+  bool bucket_events_on = false;  // recorded only when a data-parallel reducer asked for them (12 event records per step cost 0.6 %)  // recorded by the last backward of that segment (never under graph replay)
   int pe_k0 = 0, pe_kp = 0;  // patch-embedding weight rows: K0 = in_ch*patch^2 values, stored at a pitch of pe_kp (zero-padded)
   // ---- bound state ----
   bool bound = false;
@@ -887,7 +888,7 @@ int t5_stack_backward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Pa
     RC(wq.flush(c));  // this layer's weight gradients: one event, then they overlap the next layer's chain
     {  // the layer's bucket of the flat gradient buffer is final behind this point of the side stream
       const int seg = dec ? 0 : 1, bi = (int)L.size() - 1 - i;
-      if (Gflat == e->G[2] && !e->use_graph && bi < (int)e->bucket_ev[seg].size()) {
+      if (e->bucket_events_on && Gflat == e->G[2] && !e->use_graph && bi < (int)e->bucket_ev[seg].size()) {
         RC((int)hipEventRecord(e->bucket_ev[seg][bi], e->side));
         if (i == 0) e->bucket_ev_live[seg] = true;
       }
@@ -1095,6 +1096,12 @@ extern "C" int klab_engine_bucket(const klab_engine* e, int segment, int i, long
   if (!e || segment < 0 || segment > 2 || i < 0 || i >= (int)e->buckets[segment].size()) return KLAB_ERR_BADARG;
   if (off) *off = e->buckets[segment][i].off;
   if (len) *len = e->buckets[segment][i].len;
+  return KLAB_OK;
+}
+extern "C" int klab_engine_set_bucket_events(klab_engine* e, int on) {
+  if (!e) return KLAB_ERR_BADARG;
+  e->bucket_events_on = on != 0;
+  if (!on) for (auto& b : e->bucket_ev_live) b = false;
   return KLAB_OK;
 }
 extern "C" int klab_engine_bucket_wait(klab_engine* e, int segment, int i, void* stream) {
@@ -1808,7 +1815,7 @@ int swin_backward(const Ctx& c, const float* dh0, float p_in) {
       } else {
         RC(linear_wgrad(cw, dqkv, 3 * C, q.xt_in, C, M, 3 * C, C, G(ix.qw)));  // q|k|v grads adjacent
       }
-      if (!e->use_graph && swin_bucket < (int)e->bucket_ev[2].size())  // this block's GEMM-weight gradients are final
+      if (e->bucket_events_on && !e->use_graph && swin_bucket < (int)e->bucket_ev[2].size())  // this block's GEMM-weight gradients are final
         RC((int)hipEventRecord(e->bucket_ev[2][swin_bucket], cw.s));
       ++swin_bucket;
       if (side_on) RC((int)hipEventRecord(e->swin_done_ev[par], cs.s));
@@ -1828,7 +1835,7 @@ int swin_backward(const Ctx& c, const float* dh0, float p_in) {
                         0.f, nullptr, 0, c.ws()));
   RC(klab_colsum(e->sdy, C0, c.dt, (int)M0, C0, G(e->si.peb), c.ws()));
   RC(linear_wgrad(c, e->sdy, C0, e->cols, e->pe_kp, (int)M0, C0, K0, G(e->si.pew)));
-  e->bucket_ev_live[2] = !e->use_graph;
+  e->bucket_ev_live[2] = e->bucket_events_on && !e->use_graph;
   return 0;
 }
 

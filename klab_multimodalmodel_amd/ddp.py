@@ -173,6 +173,8 @@ class DistributedDataParallel(nn.Module):
         nseg = 3 if module.args.image_model_train else 2
         self.reducer = SegmentReducer(eng.segments[:nseg], process_group, max_bucket_elems, engine=eng, min_bucket_elems=min_bucket_elems)
         self._nseg = nseg
+        if hasattr(eng, "set_bucket_events"):  # per-layer ready events: only worth recording when collectives will be issued
+            eng.set_bucket_events(dist.is_initialized())
         module._direct_grads = True
         module._segment_hook = self._on_segment
         self.overlap_optimizer = bool(overlap_optimizer)

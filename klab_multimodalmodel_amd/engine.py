@@ -110,6 +110,7 @@ ENGINE_SIGS = {
     "klab_engine_num_buckets": ([C.c_void_p, C.c_int], C.c_int),
     "klab_engine_bucket": ([C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long)], C.c_int),
     "klab_engine_bucket_wait": ([C.c_void_p, C.c_int, C.c_int, C.c_void_p], C.c_int),
+    "klab_engine_set_bucket_events": ([C.c_void_p, C.c_int], C.c_int),
     "klab_engine_workspace_bytes": ([C.c_void_p, C.c_int, C.c_int, C.c_int], C.c_size_t),
     "klab_engine_bind": ([C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                           C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
@@ -361,6 +362,10 @@ class Engine:
             return
         L.check(self._lib.klab_engine_adam_step(self._h, m.data_ptr(), v.data_ptr(), lr, beta1, beta2, eps, weight_decay, bias_corr1,
                                                 bias_corr2, L.stream_ptr()), "klab_engine_adam_step")
+
+    def set_bucket_events(self, on=True):
+        """record the per-layer bucket events during backward (a data-parallel reducer is attached)"""
+        L.check(self._lib.klab_engine_set_bucket_events(self._h, int(on)), "klab_engine_set_bucket_events")
 
     def bucket_wait(self, segment, i, stream):
         """`stream` (torch.cuda.Stream) waits until layer bucket i of the last backward of `segment` is final; False when the
