@@ -163,6 +163,11 @@ def _traffic(key):
 
 
 def main():
+    # stdout carries exactly ONE JSON line: everything else that writes to file descriptor 1 while the bench runs (RCCL's
+    # version banner, library notices) is sent to stderr; the descriptor is restored for the final line
+    sys.stdout.flush()
+    _stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -300,7 +305,10 @@ def main():
         print(f"[bench] gpu leg done: {value:.1f} samples/s, {ms:.2f} ms/step", file=sys.stderr, flush=True)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+        sys.stdout.flush()
+        os.dup2(_stdout_fd, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dist_on:
         del model, core, optimizer, ddp, eng
         import gc

@@ -327,7 +327,11 @@ __device__ __forceinline__ void copy_out_tile(const GemmP& p, const char* smem, 
           continue;
         }
       }
-      *reinterpret_cast<f32x4*>(dst) = val;
+      if (p.ablate & 64) {  // experiment: write-through (sc1) stores -- nothing left dirty in L2 for the end-of-kernel release
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(val) : "memory");
+      } else {
+        *reinterpret_cast<f32x4*>(dst) = val;
+      }
     } else {
       const int epc = 1 << sh;
       const int nv = (p.N - n) < epc ? (p.N - n) : epc;
