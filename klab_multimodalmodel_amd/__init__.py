@@ -1,15 +1,13 @@
-"""MI355X-native Swin-V2 -> T5 caption-training hot path (drop-in for the reference's models/model.py)."""
-import os as _os
+"""MI355X-native Swin-V2 -> T5 caption-training hot path (drop-in for the reference's models/model.py).
 
-# The engine keeps three HIP streams busy (main, weight-gradient side stream, language-encoder side stream) next to torch's
-# and, under DDP, ProcessGroupNCCL's high-priority stream.  The ROCm runtime multiplexes streams onto GPU_MAX_HW_QUEUES
-# hardware queues (default 4); once streams share a queue the side-stream overlap is lost -- measured: merely creating the
-# RCCL process group cost +0.27 ms per 6.8 ms step with 4 queues and nothing with 8.  Read when the HIP runtime initialises,
-# so it has to be in the environment before the first HIP call; an explicit setting by the user wins.
-# Not under hipGraph replay (KLAB_GRAPH=1): the graph executor spreads nodes over every queue and measured 16.6 ms/step with 8
-# queues against 6.9 with 4.
-if _os.environ.get("KLAB_GRAPH", "0") != "1":
-    _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+Runtime configuration note (no longer applied at import: importing a library must not edit the host process's environment).
+The engine keeps three HIP streams busy (main, weight-gradient side stream, language-encoder side stream) next to torch's and,
+under DDP, ProcessGroupNCCL's stream.  The ROCm runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4);
+once streams share a queue the side-stream overlap is lost -- measured: merely creating the RCCL process group cost +0.27 ms per
+6.8 ms step with 4 queues and nothing with 8.  The variable is read when the HIP runtime initialises, so the LAUNCHER exports it
+(`GPU_MAX_HW_QUEUES=8 torchrun ... train.py`); `bench.py` and `tests/conftest.py` set it themselves before
+their first HIP call.  Not under hipGraph replay (KLAB_GRAPH=1): 16.6 ms/step with 8 queues against 6.9 with 4.
+"""
 
 __all__ = ["MyModel"]
 

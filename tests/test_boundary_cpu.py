@@ -272,3 +272,30 @@ def test_image_processor_from_pretrained_never_silently_defaults(tmp_path):
     assert q.size == 192 and q.resample == 3 and q.mean == (0.1, 0.2, 0.3)
     r = GpuImageProcessor.from_pretrained(size=224, device="cpu")  # explicit settings only
     assert r.size == 224
+
+
+def test_bench_workloads_follow_the_survey_table():
+    """bench.py's workloads = BASELINE.json configs[1..4] as SURVEY §8(d) resolves them (shapes, per-GPU batch, fwd+bwd
+    GFLOP/sample), and the span-mask batch has the grammar of the reference's RedCaps loader after tokenisation
+    (ref/modules/loader.py:56-72): sentinels 32099 - k in increasing k in the source, <extra_id_0> w.. <extra_id_k> </s> in the
+    target, zero padding, </s> closing every source row."""
+    import bench
+    w = bench.WORKLOADS
+    assert (w["caption"]["B"], w["caption"]["Ls"], w["caption"]["Lt"], w["caption"]["gflop"]) == (64, 9, 64, 27.26)
+    assert (w["cfg3"]["B"], w["cfg3"]["gflop"], w["cfg3"]["train_swin"]) == (32, 137.27, True)
+    assert (w["spanmask"]["Ls"], w["spanmask"]["Lt"], w["spanmask"]["gflop"]) == (32, 16, 118.90)
+    assert w["cfg5"]["swin"]["window_size"] == 24 and w["cfg5"]["swin"]["image_size"] == 384 and w["cfg5"]["gflop"] == 817.26
+    for name in w:
+        sw, t5 = bench.workload_configs(name)
+        assert sw.hidden_size == t5.d_model, name  # no projection between the towers (ref/models/model.py:23)
+    pix, src, tgt = bench.synth_spanmask_batch(8, 32, 16, 8, 32128, "cpu", seed=3)
+    assert pix.shape == (8, 3, 8, 8) and src.shape == (8, 32) and tgt.shape == (8, 16)
+    for b in range(8):
+        s_sent = [int(x) for x in src[b] if int(x) >= 32000]
+        t_sent = [int(x) for x in tgt[b] if int(x) >= 32000]
+        assert s_sent == [32099 - k for k in range(4)] and t_sent == [32099 - k for k in range(5)]
+        row = src[b].tolist()
+        end = row.index(1)
+        assert all(x == 0 for x in row[end + 1:]) and int(tgt[b, 0]) == 32099
+        trow = tgt[b].tolist()
+        assert 1 in trow and all(x == 0 for x in trow[trow.index(1) + 1:])
