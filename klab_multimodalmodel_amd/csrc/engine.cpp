@@ -1279,7 +1279,14 @@ extern "C" int klab_engine_bind(klab_engine* e, int B, int Ls, int Lt, void* wor
   }
   e->seed_set = false;
   if (!e->side) {
-    RC((int)hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+    {  // experiment knob: KLAB_SIDE_PRIO=low|high gives the side stream (weight gradients, language encoder) another priority
+      const char* pv = getenv("KLAB_SIDE_PRIO");
+      int lo = 0, hi = 0;
+      if (pv && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && (pv[0] == 'l' || pv[0] == 'h'))
+        RC((int)hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, pv[0] == 'l' ? lo : hi));
+      else
+        RC((int)hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+    }
     RC((int)hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     RC((int)hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     RC((int)hipStreamCreateWithFlags(&e->own, hipStreamNonBlocking));
