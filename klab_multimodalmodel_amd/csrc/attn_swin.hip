@@ -776,7 +776,12 @@ __host__ inline SwinBwdWs swin_bwd_ws(int B, int R, int w, int H, int C) {
   o.ds = off; off += large ? 0 : al((size_t)B * nW * H * n * 64 * 2);
   o.biasw = off; off += large ? 0 : al(nW * H * n * n * 4);
   // large windows: per-workgroup partials of d(bias table), [B*nW * ceil(n/64), H, (2w-1)^2] f32
-  o.dtp = off; off += large ? al((size_t)B * nW * ((n + 63) / 64) * H * (size_t)(2 * w - 1) * (2 * w - 1) * 4) : 0;
+  // (sized for both forms of the table gradient: partial tables [.., ceil(n/64), H, (2w-1)^2] f32, or dS [.., H, n, roundup32(n)] bf16)
+  {
+    const size_t part = (size_t)B * nW * ((n + 63) / 64) * H * (size_t)(2 * w - 1) * (2 * w - 1) * 4;
+    const size_t dsb = (size_t)B * nW * H * n * ((n + 31) & ~(size_t)31) * 2;
+    o.dtp = off; off += large ? al(part > dsb ? part : dsb) : 0;
+  }
   o.total = off;
   return o;
 }

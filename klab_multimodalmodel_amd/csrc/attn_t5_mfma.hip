@@ -700,10 +700,12 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(FlashP p) {
   delta += __shfl_xor(delta, 32, 64);
   const float lq = p.lse[((long)bt * p.H + h) * Lq + qc];
   const float sscale = p.score_scale ? p.score_scale[h] : 1.f;
-  const bool want_dtab = p.dbtab_part != nullptr || p.dbtab != nullptr;
+  const bool want_dtab = (p.dbtab_part != nullptr || p.dbtab != nullptr) && p.ds_ws == nullptr;
   const float* brow = nullptr;
   if constexpr (BIAS == 1) brow = p.bias + (p.bias_mod > 0 ? (long)(bt % p.bias_mod) * p.H * Lq * Lk : 0L) + ((long)h * Lq + qc) * Lk;
-  bf16_t* dsrow = (BIAS == 1 && p.ds_ws && q < Lq) ? p.ds_ws + (((long)bt * p.H + h) * Lq + q) * Lkp : nullptr;
+  // dS rows for a second-pass reduction: T5 position-bias gradient (BIAS 1) and, for Swin (BIAS 2), the table gradient -- summing
+  // dS per table entry with LDS float atomics cost 0.81 of 1.39 ms per stage-0 block (profiles/r02_swin_large_window_kernels_B8.txt)
+  bf16_t* dsrow = (BIAS != 0 && p.ds_ws && q < Lq) ? p.ds_ws + (((long)bt * p.H + h) * Lq + q) * Lkp : nullptr;
   const DropCtx dc = drop_slab(make_drop(p.seed, p.tag, p.p), (uint32_t)(bt * p.H + h));
   f32x4 acc[DT];
 #pragma unroll
@@ -770,7 +772,9 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(FlashP p) {
     }
   }
   if constexpr (BIAS == 2) {
-    if (p.dbtab_part) {
+    if (p.ds_ws) {
+      // the table gradient comes from the stored dS rows (swin_dtab_from_ds_kernel)
+    } else if (p.dbtab_part) {
       __syncthreads();
       float* dst = p.dbtab_part + (((long)bt * gridDim.x + blockIdx.x) * p.H + h) * ntab;
       for (int t = threadIdx.x; t < ntab; t += 256) dst[t] = dtab[t] + dtab[ntab + t] + dtab[2 * ntab + t] + dtab[3 * ntab + t];
@@ -1074,6 +1078,31 @@ int t5_attn_bwd_mfma_dispatch(const klab_attn_args* a, hipStream_t s) {
 static int t5_flash_fallback_fwd(const AttnMP& p, int dk, hipStream_t s) { return t5_flash_fallback(p, dk, false, s); }
 
 // Swin-V2 large windows on window-major copies (attn_swin.hip): see FlashP
+// d(table)[c, h] += sum over sequences bt and query tokens i of dS[bt, h, i, j(i, c)]: table entry c = (dy, dx) pairs query
+// (iy, ix) with key (iy - dy, ix - dx) (HF/swinv2:480-490).  One thread per table entry, consecutive entries = consecutive dx =
+// consecutive keys of one dS row (coalesced 2-byte reads); blockIdx.z splits the sequences.
+__global__ __launch_bounds__(256) void swin_dtab_from_ds_kernel(const bf16_t* __restrict__ ds, float* __restrict__ dbtab, int Bt, int H, int w,
+                                                                int Lkp) {
+  const int tw = 2 * w - 1, ntab = tw * tw, n = w * w;
+  const int c = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y;
+  if (c >= ntab) return;
+  const int dy = c / tw - (w - 1), dx = c % tw - (w - 1);
+  const int iy0 = dy > 0 ? dy : 0, iy1 = dy < 0 ? w + dy : w;  // query rows whose partner row iy - dy lies inside the window
+  const int ix0 = dx > 0 ? dx : 0, ix1 = dx < 0 ? w + dx : w;
+  const int per = (Bt + gridDim.z - 1) / gridDim.z;
+  const int b0 = blockIdx.z * per, b1 = b0 + per < Bt ? b0 + per : Bt;
+  float a = 0.f;
+  for (int bt = b0; bt < b1; ++bt) {
+    const bf16_t* base = ds + ((long)bt * H + h) * n * Lkp;
+    for (int iy = iy0; iy < iy1; ++iy) {
+      const bf16_t* row = base + (long)(iy * w) * Lkp + (iy - dy) * w - dx;  // + ix * Lkp + ix
+#pragma unroll 4
+      for (int ix = ix0; ix < ix1; ++ix) a += (float)row[(long)ix * Lkp + ix];
+    }
+  }
+  if (a != 0.f) atomicAdd(dbtab + (long)c * H + h, a);
+}
+
 int swin_flash_dispatch(const void* g, long ldg, int C, void* otok, long ldot, float* lse, int Bt, int H, int n, const float* scale,
                         const float* btab, float* dbtab, float* dbtab_part, int w, int R, int shift, int nW, const void* ow,
                         const void* dow, void* dg, int which, hipStream_t s) {
@@ -1086,12 +1115,28 @@ int swin_flash_dispatch(const void* g, long ldg, int C, void* otok, long ldot, f
   f.dout = (const bf16_t*)dow; f.lddo = C;
   bf16_t* dgb = (bf16_t*)dg;
   f.dq = dgb; f.dkk = dgb ? dgb + C : nullptr; f.dv = dgb ? dgb + 2 * C : nullptr; f.lddq = f.lddk = f.lddv = ldg;
-  f.dbtab_part = (which == 1 && dbtab) ? dbtab_part : nullptr;
-  const int rc = flash_attn_dispatch(f, 32, 2, which, s);
-  if (rc || !f.dbtab_part) return rc;
+  // d(table): `dbtab_part` is either the per-workgroup partial-table scratch (LDS-atomics form) or, with ds_mode, the dS
+  // scratch [Bt, H, n, roundup32(n)] bf16 of the store-and-reduce form
+  // measured (configs[4] stages at B = 8, tools/swin_attn_bench.py): store-and-reduce 1296 / 791 / 644 / 168 us per block backward
+  // against 1389 / 720 / 413 / 80 us for the LDS-atomics form (0.57 / 0.33 / 0.20 / 0.05 ms without any table gradient): the
+  // one-thread-per-entry reduction of 2-byte dS elements costs what the atomics cost.  Default: atomics; KLAB_SWIN_DTAB_DS=1 selects
+  // the other form.
+  static const bool ds_mode = [] { const char* e = getenv("KLAB_SWIN_DTAB_DS"); return e && atoi(e) != 0; }();
   const int ntab = (2 * w - 1) * (2 * w - 1);
-  hipLaunchKernelGGL(dbtab_reduce_kernel, dim3((unsigned)(((long)H * ntab + 255) / 256)), dim3(256), 0, s, f.dbtab_part,
-                     (long)Bt * ((n + 63) / 64), H, ntab, dbtab);
+  const bool want = which == 1 && dbtab && dbtab_part;
+  if (want && ds_mode) f.ds_ws = (bf16_t*)dbtab_part;
+  else f.dbtab_part = want ? dbtab_part : nullptr;
+  const int rc = flash_attn_dispatch(f, 32, 2, which, s);
+  if (rc || !want) return rc;
+  if (ds_mode) {
+    int gz = Bt / 8;
+    gz = gz < 1 ? 1 : (gz > 64 ? 64 : gz);
+    hipLaunchKernelGGL(swin_dtab_from_ds_kernel, dim3((unsigned)((ntab + 255) / 256), (unsigned)H, (unsigned)gz), dim3(256), 0, s,
+                       (const bf16_t*)dbtab_part, dbtab, Bt, H, w, (n + 31) & ~31);
+  } else {
+    hipLaunchKernelGGL(dbtab_reduce_kernel, dim3((unsigned)(((long)H * ntab + 255) / 256)), dim3(256), 0, s, f.dbtab_part,
+                       (long)Bt * ((n + 63) / 64), H, ntab, dbtab);
+  }
   KLAB_LAUNCH_CHECK();
   return KLAB_OK;
 }
