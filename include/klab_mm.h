@@ -169,6 +169,11 @@ typedef struct klab_swin_attn_args {
    * [(2w-1)^2, H] (zeroed by the caller).  These shapes run tiled kernels (keys streamed in blocks of 64, LDS use
    * independent of n); lse / dlogit_scale / dqkv as above.                                                         */
   const float* bias_table; float* dbias_table;
+  /* Window padding (R % w != 0, HF/swinv2:645-650, 688-690): the token grid is padded to ceil(R/w)*w with zero input rows that
+   * still act as keys -- k = 0, v = v_bias [C] (the value Linear's bias, NULL = 0) -- and are cropped from the output; their
+   * d v is added to dv_bias [C] (optional).  Padded shapes always run the tiled / streaming kernels; lse then has
+   * B * ceil(R/w)^2 * H * w*w entries.                                                                              */
+  const float* v_bias; float* dv_bias;
 } klab_swin_attn_args;
 int klab_swin_attn_fwd(const klab_swin_attn_args* a, void* stream);
 /* scratch bytes the matrix-core backward needs for this shape (0: shape outside its envelope) */

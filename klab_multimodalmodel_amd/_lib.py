@@ -41,7 +41,8 @@ class SwinAttnArgs(C.Structure):
     _fields_ = [("dtype", i32), ("qkv", vp), ("ctx", vp), ("bias", vp), ("logit_scale", vp), ("lse", vp),
                 ("B", i32), ("R", i32), ("w", i32), ("shift", i32), ("H", i32), ("C", i32),
                 ("dctx", vp), ("dqkv", vp), ("dbias", vp), ("dlogit_scale", vp),
-                ("bwd_ws", vp), ("bwd_ws_bytes", C.c_size_t), ("bias_table", vp), ("dbias_table", vp)]
+                ("bwd_ws", vp), ("bwd_ws_bytes", C.c_size_t), ("bias_table", vp), ("dbias_table", vp),
+                ("v_bias", vp), ("dv_bias", vp)]
 
 
 # every exported entry point of include/klab_mm.h: name -> argtypes (restype is always int)

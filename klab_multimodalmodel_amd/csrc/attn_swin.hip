@@ -762,7 +762,8 @@ struct SwinBwdWs {
   size_t g, dow, ow, dg, invn, scale, ds, biasw, dtp, total;
 };
 __host__ inline SwinBwdWs swin_bwd_ws(int B, int R, int w, int H, int C) {
-  const size_t M = (size_t)B * R * R, n = (size_t)w * w, nW = (size_t)(R / w) * (R / w);
+  // window-major rows: padded windows (R % w != 0) count in full
+  const size_t n = (size_t)w * w, nW = (size_t)((R + w - 1) / w) * ((R + w - 1) / w), M = (size_t)B * nW * n;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   SwinBwdWs o;
   size_t off = 0;
@@ -772,7 +773,7 @@ __host__ inline SwinBwdWs swin_bwd_ws(int B, int R, int w, int H, int C) {
   o.dg = off; off += al(M * 3 * C * 2);
   o.invn = off; off += al(M * H * 2 * 4);
   o.scale = off; off += al((size_t)H * 4);
-  const bool large = n > 64;  // streaming kernels: no dS scratch, no per-window bias+mask tensor
+  const bool large = n > 64 || (R % w) != 0;  // streaming kernels: no dS scratch, no per-window bias+mask tensor
   o.ds = off; off += large ? 0 : al((size_t)B * nW * H * n * 64 * 2);
   o.biasw = off; off += large ? 0 : al(nW * H * n * n * 4);
   // large windows: per-workgroup partials of d(bias table), [B*nW * ceil(n/64), H, (2w-1)^2] f32
@@ -790,25 +791,42 @@ struct SwinBwdP {
   const bf16_t* qkv; const bf16_t* ctx; const bf16_t* dctx; bf16_t* dqkv;
   bf16_t* g; bf16_t* dow; bf16_t* ow; const bf16_t* dg; float* invn; float* scale; const float* logit_scale; float* dlogit_scale;
   int B, R, w, shift, H, C;
+  int Rp; const float* vbias; float* dvbias;  // window padding: padded grid size, value bias (rows of padded keys) and its gradient
 };
-__device__ __forceinline__ int swin_token_of_row(long rw, int n, int nW, int nWr, int w, int R, int shift) {
+// window-major row -> source token; -1 for a padded position of the grid (HF/swinv2:645-650)
+__device__ __forceinline__ int swin_token_of_row(long rw, int n, int nW, int nWr, int w, int R, int Rp, int shift) {
   const int j = (int)(rw % n);
   const int bw = (int)(rw / n);
   const int win = bw % nW, b = bw / nW;
   const int ys = (win / nWr) * w + j / w, xs = (win % nWr) * w + j % w;
-  const int y = (ys + shift) % R, x = (xs + shift) % R;
-  return (b * R + y) * R + x;
+  const int y = (ys + shift) % Rp, x = (xs + shift) % Rp;
+  return (y < R && x < R) ? (b * R + y) * R + x : -1;
 }
 
 __global__ __launch_bounds__(256) void swin_bwd_gather_kernel(SwinBwdP p) {
-  const int C = p.C, C8 = C >> 3, n = p.w * p.w, nWr = p.R / p.w, nW = nWr * nWr;
-  const long M = (long)p.B * p.R * p.R;
+  const int C = p.C, C8 = C >> 3, n = p.w * p.w, nWr = p.Rp / p.w, nW = nWr * nWr;
+  const long M = (long)p.B * nW * n;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (blockIdx.x == 0 && (int)threadIdx.x < p.H) p.scale[threadIdx.x] = __expf(fminf(p.logit_scale[threadIdx.x], 4.6051701859880914f));
   if (idx >= M * C8) return;  // C8 is a multiple of 4: the 4 lanes of a head slice leave together
   const long rw = idx / C8;
   const int c8 = (int)(idx % C8), h = c8 >> 2;
-  const int t = swin_token_of_row(rw, n, nW, nWr, p.w, p.R, p.shift);
+  const int t = swin_token_of_row(rw, n, nW, nWr, p.w, p.R, p.Rp, p.shift);
+  if (t < 0) {  // padded position: q-hat = k-hat = 0, v = value bias, no upstream gradient
+    bf16x8 z = {}, vb = {};
+    if (p.vbias) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) vb[u] = (bf16_t)p.vbias[c8 * 8 + u];
+    }
+    bf16_t* dst = p.g + rw * 3 * C + c8 * 8;
+    *reinterpret_cast<bf16x8*>(dst) = z;
+    *reinterpret_cast<bf16x8*>(dst + C) = z;
+    *reinterpret_cast<bf16x8*>(dst + 2 * C) = vb;
+    *reinterpret_cast<bf16x8*>(p.dow + rw * C + c8 * 8) = z;
+    *reinterpret_cast<bf16x8*>(p.ow + rw * C + c8 * 8) = z;
+    if ((c8 & 3) == 0) *reinterpret_cast<float2*>(p.invn + (rw * p.H + h) * 2) = make_float2(0.f, 0.f);
+    return;
+  }
   const bf16_t* src = p.qkv + (long)t * 3 * C + c8 * 8;
   bf16x8 q = *reinterpret_cast<const bf16x8*>(src);
   bf16x8 k = *reinterpret_cast<const bf16x8*>(src + C);
@@ -834,14 +852,26 @@ __global__ __launch_bounds__(256) void swin_bwd_gather_kernel(SwinBwdP p) {
 
 // forward flavour of the gather: window-major unit-q | unit-k | v only (the streaming forward of large windows)
 __global__ __launch_bounds__(256) void swin_fwd_gather_kernel(SwinBwdP p) {
-  const int C = p.C, C8 = C >> 3, n = p.w * p.w, nWr = p.R / p.w, nW = nWr * nWr;
-  const long M = (long)p.B * p.R * p.R;
+  const int C = p.C, C8 = C >> 3, n = p.w * p.w, nWr = p.Rp / p.w, nW = nWr * nWr;
+  const long M = (long)p.B * nW * n;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (blockIdx.x == 0 && (int)threadIdx.x < p.H) p.scale[threadIdx.x] = __expf(fminf(p.logit_scale[threadIdx.x], 4.6051701859880914f));
   if (idx >= M * C8) return;
   const long rw = idx / C8;
   const int c8 = (int)(idx % C8);
-  const int t = swin_token_of_row(rw, n, nW, nWr, p.w, p.R, p.shift);
+  const int t = swin_token_of_row(rw, n, nW, nWr, p.w, p.R, p.Rp, p.shift);
+  if (t < 0) {  // padded position: k-hat = 0, v = value bias
+    bf16x8 z = {}, vb = {};
+    if (p.vbias) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) vb[u] = (bf16_t)p.vbias[c8 * 8 + u];
+    }
+    bf16_t* dst = p.g + rw * 3 * C + c8 * 8;
+    *reinterpret_cast<bf16x8*>(dst) = z;
+    *reinterpret_cast<bf16x8*>(dst + C) = z;
+    *reinterpret_cast<bf16x8*>(dst + 2 * C) = vb;
+    return;
+  }
   const bf16_t* src = p.qkv + (long)t * 3 * C + c8 * 8;
   bf16x8 q = *reinterpret_cast<const bf16x8*>(src);
   bf16x8 k = *reinterpret_cast<const bf16x8*>(src + C);
@@ -875,15 +905,22 @@ __global__ __launch_bounds__(256) void swin_bias_mask_kernel(const float* __rest
 
 __global__ __launch_bounds__(256) void swin_bwd_scatter_kernel(SwinBwdP p) {
   __shared__ float dsc[64];
-  const int C = p.C, C8 = C >> 3, n = p.w * p.w, nWr = p.R / p.w, nW = nWr * nWr, H = p.H;
-  const long M = (long)p.B * p.R * p.R;
+  const int C = p.C, C8 = C >> 3, n = p.w * p.w, nWr = p.Rp / p.w, nW = nWr * nWr, H = p.H;
+  const long M = (long)p.B * nW * n;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (threadIdx.x < 64) dsc[threadIdx.x] = 0.f;
   __syncthreads();
-  if (idx < M * C8) {
+  const int tchk = idx < M * C8 ? swin_token_of_row(idx / C8, n, nW, nWr, p.w, p.R, p.Rp, p.shift) : 0;
+  if (idx < M * C8 && tchk < 0) {  // padded key: its d v is part of the value-bias gradient; nothing else flows back
+    if (p.dvbias) {
+      const bf16x8 dv = *reinterpret_cast<const bf16x8*>(p.dg + (idx / C8) * 3 * C + 2 * C + (idx % C8) * 8);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) atomicAdd(p.dvbias + (idx % C8) * 8 + u, (float)dv[u]);
+    }
+  } else if (idx < M * C8) {
     const long rw = idx / C8;
     const int c8 = (int)(idx % C8), h = c8 >> 2;
-    const int t = swin_token_of_row(rw, n, nW, nWr, p.w, p.R, p.shift);
+    const int t = tchk;
     const bf16_t* gs = p.g + rw * 3 * C + c8 * 8;
     const bf16_t* ds = p.dg + rw * 3 * C + c8 * 8;
     const bf16x8 qh = *reinterpret_cast<const bf16x8*>(gs), kh = *reinterpret_cast<const bf16x8*>(gs + C);
@@ -919,7 +956,7 @@ __global__ __launch_bounds__(256) void swin_bwd_scatter_kernel(SwinBwdP p) {
 
 int t5_attn_bwd_mfma_dispatch(const klab_attn_args* a, hipStream_t s);  // attn_t5_mfma.hip
 int swin_flash_dispatch(const void* g, long ldg, int C, void* otok, long ldot, float* lse, int Bt, int H, int n, const float* scale,
-                        const float* btab, float* dbtab, float* dbtab_part, int w, int R, int shift, int nW, const void* ow,
+                        const float* btab, float* dbtab, float* dbtab_part, int w, int Rp, int Rreal, int shift, int nW, const void* ow,
                         const void* dow, void* dg, int which, hipStream_t s);
 int dbias_reduce_dispatch(const void* ds_ws, float* dbias, int nbatch, int H, int Lq, int Lk, hipStream_t s);
 
@@ -960,11 +997,11 @@ int cpb_table_launch(const float* coords, const float* w0, const float* b0, cons
 }
 }  // namespace klab
 // windows of more than 64 tokens, or a bias supplied as the (2w-1)^2 x H table: the tiled kernels of attn_swin_large.hip
-static bool swin_use_large(const klab_swin_attn_args* a) { return a->w * a->w > 64 || (!a->bias && a->bias_table); }
+static bool swin_use_large(const klab_swin_attn_args* a) { return a->w * a->w > 64 || (a->R % a->w) != 0 || (!a->bias && a->bias_table); }
 
 static int swin_args_ok(const klab_swin_attn_args* a) {
   if (!a || !a->qkv || !a->ctx || (!a->bias && !a->bias_table) || !a->logit_scale) return KLAB_ERR_BADARG;
-  if (a->w <= 0 || a->R % a->w) return KLAB_ERR_UNSUPPORTED;  // padded windows (HF/swinv2:645-650) are out of scope
+  if (a->w <= 0) return KLAB_ERR_BADARG;  // (R % w != 0: padded windows, HF/swinv2:645-650 -- the tiled / streaming kernels)
   if (a->C % a->H) return KLAB_ERR_BADARG;
   if (a->shift < 0 || a->shift >= a->w) return KLAB_ERR_BADARG;
   return KLAB_OK;
@@ -1003,12 +1040,13 @@ static bool swin_bwd_mfma_ok(int dtype, int w, int H, int C) { return dtype == K
 // windows of more than 64 tokens on the matrix cores: streaming kernels over window-major copies (bf16, head dim 32, bias table)
 static bool swin_flash_ok(int dtype, int w, int H, int C) {
   static const bool on = [] { const char* e = getenv("KLAB_SWIN_FLASH"); return !e || atoi(e) != 0; }();
-  return on && dtype == KLAB_BF16 && C == H * 32 && w * w > 64 && H <= 64 && (C & 7) == 0;
+  return on && dtype == KLAB_BF16 && C == H * 32 && H <= 64 && (C & 7) == 0 && w > 0;
 }
 
 extern "C" size_t klab_swin_attn_bwd_ws_bytes(int dtype, int B, int R, int w, int H, int C) {
-  if (B <= 0 || R <= 0 || w <= 0 || R % w) return 0;
-  if (!swin_bwd_mfma_ok(dtype, w, H, C) && !swin_flash_ok(dtype, w, H, C)) return 0;
+  if (B <= 0 || R <= 0 || w <= 0) return 0;
+  const bool large = w * w > 64 || (R % w) != 0;
+  if (large ? !swin_flash_ok(dtype, w, H, C) : !swin_bwd_mfma_ok(dtype, w, H, C)) return 0;
   return swin_bwd_ws(B, R, w, H, C).total;
 }
 
@@ -1016,24 +1054,26 @@ static int swin_attn_flash(const klab_swin_attn_args* a, bool backward, hipStrea
   const SwinBwdWs L = swin_bwd_ws(a->B, a->R, a->w, a->H, a->C);
   if (a->bwd_ws_bytes < L.total) return KLAB_ERR_BADARG;
   char* ws = (char*)a->bwd_ws;
-  const int n = a->w * a->w, nW = (a->R / a->w) * (a->R / a->w), C = a->C, H = a->H;
+  const int nWr_ = (a->R + a->w - 1) / a->w;
+  const int n = a->w * a->w, nW = nWr_ * nWr_, C = a->C, H = a->H;
   SwinBwdP p{(const bf16_t*)a->qkv, (const bf16_t*)a->ctx, (const bf16_t*)a->dctx, (bf16_t*)a->dqkv,
              (bf16_t*)(ws + L.g), (bf16_t*)(ws + L.dow), (bf16_t*)(ws + L.ow), (const bf16_t*)(ws + L.dg), (float*)(ws + L.invn),
-             (float*)(ws + L.scale), a->logit_scale, a->dlogit_scale, a->B, a->R, a->w, a->shift, H, C};
-  const long work = (long)a->B * a->R * a->R * (C / 8);
+             (float*)(ws + L.scale), a->logit_scale, a->dlogit_scale, a->B, a->R, a->w, a->shift, H, C,
+             nWr_ * a->w, a->v_bias, a->dv_bias};
+  const long work = (long)a->B * nW * n * (C / 8);
   const unsigned nb = (unsigned)((work + 255) / 256);
   if (!backward) {
     hipLaunchKernelGGL(swin_fwd_gather_kernel, dim3(nb), dim3(256), 0, s, p);
     KLAB_LAUNCH_CHECK();
     return swin_flash_dispatch(ws + L.g, 3L * C, C, a->ctx, C, a->lse, a->B * nW, H, n, (const float*)(ws + L.scale), a->bias_table, nullptr,
-                               nullptr, a->w, a->R, a->shift, nW, nullptr, nullptr, nullptr, 0, s);
+                               nullptr, a->w, nWr_ * a->w, a->R, a->shift, nW, nullptr, nullptr, nullptr, 0, s);
   }
   hipLaunchKernelGGL(swin_bwd_gather_kernel, dim3(nb), dim3(256), 0, s, p);
   KLAB_LAUNCH_CHECK();
   for (int which = 1; which <= 2; ++which) {
     const int rc = swin_flash_dispatch(ws + L.g, 3L * C, C, nullptr, 0, a->lse, a->B * nW, H, n, (const float*)(ws + L.scale), a->bias_table,
-                                       a->dbias_table, (float*)(ws + L.dtp), a->w, a->R, a->shift, nW, ws + L.ow, ws + L.dow, ws + L.dg,
-                                       which, s);
+                                       a->dbias_table, (float*)(ws + L.dtp), a->w, nWr_ * a->w, a->R, a->shift, nW, ws + L.ow, ws + L.dow,
+                                       ws + L.dg, which, s);
     if (rc) return rc;
   }
   hipLaunchKernelGGL(swin_bwd_scatter_kernel, dim3(nb), dim3(256), 0, s, p);
@@ -1048,7 +1088,7 @@ static int swin_attn_bwd_mfma(const klab_swin_attn_args* a, hipStream_t s) {
   const int n = a->w * a->w, nW = (a->R / a->w) * (a->R / a->w), C = a->C, H = a->H;
   SwinBwdP p{(const bf16_t*)a->qkv, (const bf16_t*)a->ctx, (const bf16_t*)a->dctx, (bf16_t*)a->dqkv,
              (bf16_t*)(ws + L.g), (bf16_t*)(ws + L.dow), (bf16_t*)(ws + L.ow), (const bf16_t*)(ws + L.dg), (float*)(ws + L.invn),
-             (float*)(ws + L.scale), a->logit_scale, a->dlogit_scale, a->B, a->R, a->w, a->shift, H, C};
+             (float*)(ws + L.scale), a->logit_scale, a->dlogit_scale, a->B, a->R, a->w, a->shift, H, C, a->R, nullptr, nullptr};
   const long work = (long)a->B * a->R * a->R * (C / 8);
   const unsigned nb = (unsigned)((work + 255) / 256);
   hipLaunchKernelGGL(swin_bwd_gather_kernel, dim3(nb), dim3(256), 0, s, p);

@@ -28,6 +28,9 @@ struct SwinLP {
   const void* qkv; void* ctx; const float* bias; const float* btab; const float* logit_scale; float* lse;
   int B, R, w, shift, H, C;
   const void* dctx; void* dqkv; float* dbias; float* dbtab; float* dlogit_scale;
+  // window padding (HF/swinv2:645-650): the grid is padded to Rp = ceil(R / w) * w with ZERO input rows, which still act as
+  // keys -- k = 0 (no key bias), v = the value bias -- and are cropped from the output
+  int Rp; const float* vbias; float* dvbias;
 };
 
 __device__ __forceinline__ int swin_region_l(int s, int R, int w, int shift) { return (s >= R - w) + (s >= R - shift); }
@@ -38,16 +41,16 @@ __device__ __forceinline__ float wave_sum_l(float v) {
   return v;
 }
 
-// window-local index j of window (wy, wx) of image b -> source token, mask region, bias code
+// window-local index j of window (wy, wx) of image b -> source token (-1: a padded position), mask region, bias code
 struct TokInfo { int tok, reg, code; };
 __device__ __forceinline__ TokInfo tok_info(const SwinLP& p, int b, int wy, int wx, int j) {
-  const int w = p.w, R = p.R;
+  const int w = p.w, R = p.R, Rp = p.Rp;
   const int jy = j / w, jx = j - jy * w;
-  const int ys = wy * w + jy, xs = wx * w + jx;                 // coordinates in the rolled image
-  const int y = (ys + p.shift) % R, x = (xs + p.shift) % R;     // torch.roll(-shift) source (HF/swinv2:667-670)
+  const int ys = wy * w + jy, xs = wx * w + jx;                 // coordinates in the rolled (padded) grid
+  const int y = (ys + p.shift) % Rp, x = (xs + p.shift) % Rp;   // torch.roll(-shift) source (HF/swinv2:667-670)
   TokInfo t;
-  t.tok = (b * R + y) * R + x;
-  t.reg = p.shift > 0 ? swin_region_l(ys, R, w, p.shift) * 3 + swin_region_l(xs, R, w, p.shift) : 0;
+  t.tok = (y < R && x < R) ? (b * R + y) * R + x : -1;
+  t.reg = p.shift > 0 ? swin_region_l(ys, Rp, w, p.shift) * 3 + swin_region_l(xs, Rp, w, p.shift) : 0;  // regions of the padded grid (:675)
   t.code = jy * (2 * w - 1) + jx;
   return t;
 }
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(64) void swin_attn_fwd_tiled(SwinLP p) {
   using V = typename Vec16L<T>::type;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int w = p.w, n = w * w, R = p.R, C = p.C, H = p.H;
-  const int nWr = R / w, nW = nWr * nWr, nqb = (n + 63) / 64, ntab = (2 * w - 1) * (2 * w - 1);
+  const int nWr = p.Rp / w, nW = nWr * nWr, nqb = (n + 63) / 64, ntab = (2 * w - 1) * (2 * w - 1);
   T* Kn = reinterpret_cast<T*>(smem);
   T* Vs = Kn + (size_t)KBLK * KST;
   int* kcode = reinterpret_cast<int*>(Vs + (size_t)KBLK * KST);
@@ -85,8 +88,9 @@ __global__ __launch_bounds__(64) void swin_attn_fwd_tiled(SwinLP p) {
     for (int t = lane; t < ntab; t += 64) tab[t] = p.btab[(long)t * H + h];
 
   const int i = qb * 64 + lane;
-  const bool valid = i < n;
-  const TokInfo qi = tok_info(p, b, wy, wx, valid ? i : n - 1);
+  TokInfo qi = tok_info(p, b, wy, wx, i < n ? i : n - 1);
+  const bool valid = i < n && qi.tok >= 0;  // padded positions are cropped from the output (HF/swinv2:688-690)
+  if (qi.tok < 0) qi.tok = 0;
   const float scale = __expf(fminf(p.logit_scale[h], 4.6051701859880914f));  // clamp at ln(100) (HF/swinv2:416)
   float qn[HD];
   {
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(64) void swin_attn_fwd_tiled(SwinLP p) {
     for (int c = 0; c < HD; ++c) qn[c] = to_f32(from_f32<T>(qn[c] * inv)) * scale;  // operand-dtype rounding before the scale
   }
   const int coff = qi.code + 2 * w * (w - 1);
-  const float* br = p.bias ? p.bias + ((long)h * n + (valid ? i : n - 1)) * n : nullptr;
+  const float* br = p.bias ? p.bias + ((long)h * n + (i < n ? i : n - 1)) * n : nullptr;
   float m = -INFINITY, l = 0.f;
   float o[HD];
 #pragma unroll
@@ -116,6 +120,13 @@ __global__ __launch_bounds__(64) void swin_attn_fwd_tiled(SwinLP p) {
       if (j < n) {
         const TokInfo kj = tok_info(p, b, wy, wx, j);
         kcode[lane] = kj.code; kreg[lane] = kj.reg;
+        if (kj.tok < 0) {  // padded key: zero input row => k = 0 (F.normalize(0) = 0), v = value bias
+#pragma unroll
+          for (int c = 0; c < HD; ++c) {
+            Kn[lane * KST + c] = from_f32<T>(0.f);
+            Vs[lane * KST + c] = from_f32<T>(p.vbias ? p.vbias[h * HD + c] : 0.f);
+          }
+        } else {
         const T* kr = qkv + (long)kj.tok * ld + C + h * HD;
         const T* vr = qkv + (long)kj.tok * ld + 2 * C + h * HD;
         float kf[HD];
@@ -134,6 +145,7 @@ __global__ __launch_bounds__(64) void swin_attn_fwd_tiled(SwinLP p) {
 #pragma unroll
           for (int u = 0; u < VEC; ++u) ov[u] = from_f32<T>(kf[c + u] * inv);
           *reinterpret_cast<V*>(Kn + lane * KST + c) = ov;
+        }
         }
       }
     }
@@ -186,7 +198,7 @@ __global__ __launch_bounds__(64) void swin_attn_bwd_dq_tiled(SwinLP p) {
   using V = typename Vec16L<T>::type;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int w = p.w, n = w * w, R = p.R, C = p.C, H = p.H;
-  const int nWr = R / w, nW = nWr * nWr, nqb = (n + 63) / 64, ntab = (2 * w - 1) * (2 * w - 1);
+  const int nWr = p.Rp / w, nW = nWr * nWr, nqb = (n + 63) / 64, ntab = (2 * w - 1) * (2 * w - 1);
   T* Kn = reinterpret_cast<T*>(smem);
   T* Vs = Kn + (size_t)KBLK * KST;
   int* kcode = reinterpret_cast<int*>(Vs + (size_t)KBLK * KST);
@@ -206,9 +218,10 @@ __global__ __launch_bounds__(64) void swin_attn_bwd_dq_tiled(SwinLP p) {
     for (int t = lane; t < ntab; t += 64) { tab[t] = p.btab[(long)t * H + h]; dtab[t] = 0.f; }
 
   const int i = qb * 64 + lane;
-  const bool valid = i < n;
-  const int ic = valid ? i : n - 1;
-  const TokInfo qi = tok_info(p, b, wy, wx, ic);
+  const int ic = i < n ? i : n - 1;
+  TokInfo qi = tok_info(p, b, wy, wx, ic);
+  const bool valid = i < n && qi.tok >= 0;  // padded queries: cropped output, no gradient
+  if (qi.tok < 0) qi.tok = 0;
   const float lsv = p.logit_scale[h];
   const bool clamped = lsv > 4.6051701859880914f;
   const float scale = __expf(fminf(lsv, 4.6051701859880914f));
@@ -251,6 +264,13 @@ __global__ __launch_bounds__(64) void swin_attn_bwd_dq_tiled(SwinLP p) {
       if (j < n) {
         const TokInfo kj = tok_info(p, b, wy, wx, j);
         kcode[lane] = kj.code; kreg[lane] = kj.reg;
+        if (kj.tok < 0) {  // padded key: zero input row => k = 0 (F.normalize(0) = 0), v = value bias
+#pragma unroll
+          for (int c = 0; c < HD; ++c) {
+            Kn[lane * KST + c] = from_f32<T>(0.f);
+            Vs[lane * KST + c] = from_f32<T>(p.vbias ? p.vbias[h * HD + c] : 0.f);
+          }
+        } else {
         const T* kr = qkv + (long)kj.tok * ld + C + h * HD;
         const T* vr = qkv + (long)kj.tok * ld + 2 * C + h * HD;
         float kf[HD];
@@ -269,6 +289,7 @@ __global__ __launch_bounds__(64) void swin_attn_bwd_dq_tiled(SwinLP p) {
 #pragma unroll
           for (int u = 0; u < VEC; ++u) ov[u] = from_f32<T>(kf[c + u] * inv);
           *reinterpret_cast<V*>(Kn + lane * KST + c) = ov;
+        }
         }
       }
     }
@@ -334,7 +355,7 @@ __global__ __launch_bounds__(64) void swin_attn_bwd_dkv_tiled(SwinLP p) {
   using V = typename Vec16L<T>::type;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int w = p.w, n = w * w, R = p.R, C = p.C, H = p.H;
-  const int nWr = R / w, nW = nWr * nWr, nkb = (n + 63) / 64, ntab = (2 * w - 1) * (2 * w - 1);
+  const int nWr = p.Rp / w, nW = nWr * nWr, nkb = (n + 63) / 64, ntab = (2 * w - 1) * (2 * w - 1);
   T* Qn = reinterpret_cast<T*>(smem);
   T* dOs = Qn + (size_t)KBLK * KST;
   float* qlse = reinterpret_cast<float*>(dOs + (size_t)KBLK * KST);
@@ -357,10 +378,14 @@ __global__ __launch_bounds__(64) void swin_attn_bwd_dkv_tiled(SwinLP p) {
   const bool valid = j < n;
   const int jc = valid ? j : n - 1;
   const TokInfo kj = tok_info(p, b, wy, wx, jc);
+  const bool kpad = kj.tok < 0;  // padded key: k = 0, v = value bias; its d v belongs to the value-bias gradient
   const float scale = __expf(fminf(p.logit_scale[h], 4.6051701859880914f));
   float kh[HD], vj[HD];
-  float kinv;
-  {
+  float kinv = 0.f;
+  if (kpad) {
+#pragma unroll
+    for (int c = 0; c < HD; ++c) { kh[c] = 0.f; vj[c] = to_f32(from_f32<T>(p.vbias ? p.vbias[h * HD + c] : 0.f)); }
+  } else {
     const T* kr = qkv + (long)kj.tok * ld + C + h * HD;
     const T* vr = qkv + (long)kj.tok * ld + 2 * C + h * HD;
     float ss = 0.f;
@@ -384,8 +409,15 @@ __global__ __launch_bounds__(64) void swin_attn_bwd_dkv_tiled(SwinLP p) {
     __syncthreads();
     {
       const int i = i0 + lane;
-      if (i < n) {
-        const TokInfo qi = tok_info(p, b, wy, wx, i);
+      const TokInfo qi0 = tok_info(p, b, wy, wx, i < n ? i : n - 1);
+      if (i < n && qi0.tok < 0) {  // padded query: P row = 0 (lse = +inf), nothing flows back through it
+        qcode[lane] = qi0.code; qreg[lane] = qi0.reg;
+#pragma unroll
+        for (int c = 0; c < HD; ++c) { Qn[lane * KST + c] = from_f32<T>(0.f); dOs[lane * KST + c] = from_f32<T>(0.f); }
+        qlse[lane] = INFINITY;
+        qdel[lane] = 0.f;
+      } else if (i < n) {
+        const TokInfo qi = qi0;
         qcode[lane] = qi.code; qreg[lane] = qi.reg;
         const T* qr = qkv + (long)qi.tok * ld + h * HD;
         const T* dor = reinterpret_cast<const T*>(p.dctx) + (long)qi.tok * C + h * HD;
@@ -439,7 +471,12 @@ __global__ __launch_bounds__(64) void swin_attn_bwd_dkv_tiled(SwinLP p) {
       }
     }
   }
-  if (valid) {  // through k-hat = k / ||k||
+  if (valid && kpad) {
+    if (p.dvbias) {
+#pragma unroll
+      for (int c = 0; c < HD; ++c) atomicAdd(p.dvbias + h * HD + c, dv[c]);
+    }
+  } else if (valid) {  // through k-hat = k / ||k||
     float dot = 0.f;
 #pragma unroll
     for (int c = 0; c < HD; ++c) dot += kh[c] * dkh[c];
@@ -521,7 +558,7 @@ static size_t tiled_lds(int ntab, bool table, int mode) {
 
 template <typename T, int HD>
 static int launch_tiled(const SwinLP& p, bool backward, hipStream_t s) {
-  const int n = p.w * p.w, nW = (p.R / p.w) * (p.R / p.w), nb = (n + 63) / 64, ntab = (2 * p.w - 1) * (2 * p.w - 1);
+  const int n = p.w * p.w, nW = (p.Rp / p.w) * (p.Rp / p.w), nb = (n + 63) / 64, ntab = (2 * p.w - 1) * (2 * p.w - 1);
   const bool table = p.btab != nullptr;
   const unsigned grid = (unsigned)((long)p.B * nW * p.H * nb);
   if (!backward) {
@@ -550,7 +587,8 @@ static int launch_tiled(const SwinLP& p, bool backward, hipStream_t s) {
 int swin_attn_large_dispatch(const klab_swin_attn_args* a, bool backward, hipStream_t s) {
   if (!a->bias && !a->bias_table) return KLAB_ERR_BADARG;
   SwinLP p{a->qkv, a->ctx, a->bias, a->bias ? nullptr : a->bias_table, a->logit_scale, a->lse, a->B, a->R, a->w, a->shift, a->H, a->C,
-           a->dctx, a->dqkv, a->bias ? a->dbias : nullptr, a->bias ? nullptr : a->dbias_table, a->dlogit_scale};
+           a->dctx, a->dqkv, a->bias ? a->dbias : nullptr, a->bias ? nullptr : a->dbias_table, a->dlogit_scale,
+           (a->R + a->w - 1) / a->w * a->w, a->v_bias, a->dv_bias};
   const int hd = a->C / a->H;
   if (a->dtype == KLAB_BF16) {
     if (a->C & 7) return KLAB_ERR_UNSUPPORTED;

@@ -491,7 +491,8 @@ struct FlashP {
   int Bt, H, Lq, Lk;
   const float* score_scale;   // [H] or null
   const float* bias; int bias_mod;
-  const float* btab; float* dbtab; int w, R, shift, nW;
+  const float* btab; float* dbtab; int w, R, shift, nW;  // R = side of the (padded) token grid the windows tile
+  int Rreal;                                              // side of the real grid: positions beyond it are padding (no output)
   float* dbtab_part;  // [Bt * ceil(Lq/64), H, ntab]: every d-q workgroup stores its table partial here (plain stores; one
                       // reduction afterwards) -- flushing 4608 workgroups x 2209 entries with global atomics onto 8.8 k
                       // addresses cost more than the whole rest of the kernel
@@ -509,10 +510,11 @@ __device__ __forceinline__ void flash_tok(const FlashP& p, int win, int i, int& 
   code = iy * (2 * w - 1) + ix;
   reg = p.shift > 0 ? flash_region((win / nWr) * w + iy, p.R, w, p.shift) * 3 + flash_region((win % nWr) * w + ix, p.R, w, p.shift) : 0;
 }
-__device__ __forceinline__ long flash_token_row(const FlashP& p, int bt, int i) {
+__device__ __forceinline__ long flash_token_row(const FlashP& p, int bt, int i) {  // -1: a padded position
   const int w = p.w, nWr = p.R / w, win = bt % p.nW, b = bt / p.nW;
   const int ys = (win / nWr) * w + i / w, xs = (win % nWr) * w + i % w;
-  return ((long)b * p.R + (ys + p.shift) % p.R) * p.R + (xs + p.shift) % p.R;
+  const int y = (ys + p.shift) % p.R, x = (xs + p.shift) % p.R;
+  return (y < p.Rreal && x < p.Rreal) ? ((long)b * p.Rreal + y) * p.Rreal + x : -1;
 }
 
 constexpr int FKB = 64;  // rows per streamed block
@@ -645,7 +647,7 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(FlashP p) {
       const int d = dt * 16 + g * 4;
       const bf16x4 ov = bf16x4{(bf16_t)(o[dt][0] * inv), (bf16_t)(o[dt][1] * inv), (bf16_t)(o[dt][2] * inv), (bf16_t)(o[dt][3] * inv)};
       if (p.o) *reinterpret_cast<bf16x4*>(p.o + (qrow0 + q) * p.ldo + (long)h * DK + d) = ov;
-      if (BIAS == 2 && p.otok) *reinterpret_cast<bf16x4*>(p.otok + trow * p.ldot + (long)h * DK + d) = ov;
+      if (BIAS == 2 && p.otok && trow >= 0) *reinterpret_cast<bf16x4*>(p.otok + trow * p.ldot + (long)h * DK + d) = ov;
     }
   }
 }
@@ -1104,14 +1106,14 @@ __global__ __launch_bounds__(256) void swin_dtab_from_ds_kernel(const bf16_t* __
 }
 
 int swin_flash_dispatch(const void* g, long ldg, int C, void* otok, long ldot, float* lse, int Bt, int H, int n, const float* scale,
-                        const float* btab, float* dbtab, float* dbtab_part, int w, int R, int shift, int nW, const void* ow,
+                        const float* btab, float* dbtab, float* dbtab_part, int w, int Rp, int Rreal, int shift, int nW, const void* ow,
                         const void* dow, void* dg, int which, hipStream_t s) {
   FlashP f;
   memset(&f, 0, sizeof(f));
   const bf16_t* gb = (const bf16_t*)g;
   f.q = gb; f.k = gb + C; f.v = gb + 2 * C; f.ldq = f.ldk = f.ldv = ldg;
   f.o = (bf16_t*)ow; f.ldo = C; f.otok = (bf16_t*)otok; f.ldot = ldot; f.lse = lse;
-  f.Bt = Bt; f.H = H; f.Lq = f.Lk = n; f.score_scale = scale; f.btab = btab; f.dbtab = dbtab; f.w = w; f.R = R; f.shift = shift; f.nW = nW;
+  f.Bt = Bt; f.H = H; f.Lq = f.Lk = n; f.score_scale = scale; f.btab = btab; f.dbtab = dbtab; f.w = w; f.R = Rp; f.Rreal = Rreal; f.shift = shift; f.nW = nW;
   f.dout = (const bf16_t*)dow; f.lddo = C;
   bf16_t* dgb = (bf16_t*)dg;
   f.dq = dgb; f.dkk = dgb ? dgb + C : nullptr; f.dv = dgb ? dgb + 2 * C : nullptr; f.lddq = f.lddk = f.lddv = ldg;

@@ -526,7 +526,8 @@ size_t plan_workspace(klab_engine* e, void* base, int B, int Ls, int Lt) {
     const long C = C0 << st, M = (long)B * R * R, F = (long)s.mlp_ratio * C;
     const int H = s.heads[st];
     const int w = R < s.window ? R : s.window;
-    const int n = w * w, nW = (R / (w > 0 ? w : 1)) * (R / (w > 0 ? w : 1));
+    const int nWr = (R + (w > 0 ? w : 1) - 1) / (w > 0 ? w : 1);  // padded windows count in full (HF/swinv2:645-650)
+    const int n = w * w, nW = nWr * nWr;
     const int ntab = (2 * w - 1) * (2 * w - 1);
     if (M * C > maxMC) maxMC = M * C;
     SwinStageBufs& sb = e->sw[st];
@@ -543,7 +544,7 @@ size_t plan_workspace(klab_engine* e, void* base, int B, int Ls, int Lt) {
       q.a = b.take((size_t)M * F * es); q.fo = b.take((size_t)M * C * es);
       q.mean2 = (float*)b.take((size_t)M * 4); q.rstd2 = (float*)b.take((size_t)M * 4);
       q.h2 = (float*)b.take((size_t)M * C * 4); q.h2t = b.take((size_t)M * C * es);
-      const bool big = n > 64;  // tiled attention kernels with the bias as a table (attn_swin_large.hip)
+      const bool big = n > 64 || (R % w) != 0;  // tiled / streaming attention kernels with the bias as a table (attn_swin_large.hip)
       q.bias = big ? nullptr : (float*)b.take((size_t)H * n * n * 4);
       q.btab = big ? (float*)b.take((size_t)ntab * H * 4) : nullptr;
       q.table = (float*)b.take((size_t)ntab * H * 4);
@@ -588,7 +589,7 @@ size_t plan_workspace(klab_engine* e, void* base, int B, int Ls, int Lt) {
       size_t need = 0;
       for (int st = 0; st < s.n_stages; ++st) {
         const int R = R0 >> st; const int w = R < s.window ? R : s.window;
-        if (!c.train_swin && w * w <= 64) continue;  // frozen tower, one-tile window: the forward kernels need no scratch
+        if (!c.train_swin && w * w <= 64 && R % w == 0) continue;  // frozen tower, one-tile unpadded window: the forward kernels need no scratch
         const size_t x = klab_swin_attn_bwd_ws_bytes(c.dtype, B, R, w, s.heads[st], s.embed_dim << st);
         if (x > need) need = x;  // (0: that stage is outside the matrix-core envelope and runs its own kernels)
       }
@@ -959,6 +960,7 @@ int swin_forward(const Ctx& c, const float* pixels, float p_in, bool refresh_bia
         a.dtype = c.dt; a.qkv = q.qkv; a.ctx = q.ctx; a.bias = q.bias; a.bias_table = q.btab; a.logit_scale = W[ix.ls]; a.lse = q.lse;
         a.B = B; a.R = q.R; a.w = q.w; a.shift = q.shift; a.H = q.H; a.C = C;
         a.bwd_ws = e->sattn_ws; a.bwd_ws_bytes = e->sattn_ws_bytes;  // (large windows: window-major copies for the streaming kernel)
+        a.v_bias = qkvb ? qkvb + 2 * C : nullptr;                     // (padded windows: rows of the padded keys)
         RC(klab_swin_attn_fwd(&a, c.ws()));
       }
       static const bool fused_proj = [] { const char* v = getenv("KLAB_SWIN_FUSED_PROJ"); return !v || atoi(v) != 0; }();
@@ -1150,7 +1152,7 @@ extern "C" int klab_engine_bind(klab_engine* e, int B, int Ls, int Lt, void* wor
     e->swin_coords[st] = (const float*)swin_coords[st];
     e->swin_index[st] = (const int*)swin_index[st];
     const int R = R0 >> st, w = R < s.window ? R : s.window;
-    if (w <= 0 || R % w) return KLAB_ERR_UNSUPPORTED;
+    if (w <= 0) return KLAB_ERR_UNSUPPORTED;
     e->swin_ntab[st] = (2 * w - 1) * (2 * w - 1);
   }
   // cast descriptors: {src, dst_off, n4_prefix}
@@ -1785,6 +1787,7 @@ int swin_backward(const Ctx& c, const float* dh0, float p_in) {
       a.B = B; a.R = q.R; a.w = q.w; a.shift = q.shift; a.H = q.H; a.C = C;
       a.dctx = e->sdctx; a.dqkv = dqkv; a.dlogit_scale = G(ix.ls);
       a.bwd_ws = e->sattn_ws; a.bwd_ws_bytes = e->sattn_ws_bytes;
+      if (ix.vb >= 0) { a.v_bias = e->farena + P[ix.vb].farena_off; a.dv_bias = G(ix.vb); }  // padded windows
       if (q.btab) {  // large window: the bias gradient is accumulated per table entry
         RC((int)hipMemsetAsync(e->sdbtab, 0, (size_t)e->swin_ntab[st] * q.H * 4, c.s));
         a.dbias_table = e->sdbtab;

@@ -170,8 +170,9 @@ def t5_attn_bwd(q, k, v, ctx, lse, dctx, dq, dk_out, dv, *, B, H, Lq, Lk, dk, bi
     L.check(lib.klab_t5_attn_bwd(C.byref(a), L.stream_ptr()), "klab_t5_attn_bwd")
 
 
-def _swin_args(qkv, ctx, bias, logit_scale, lse, B, R, w, shift, H, Cc, bias_table=None):
+def _swin_args(qkv, ctx, bias, logit_scale, lse, B, R, w, shift, H, Cc, bias_table=None, v_bias=None, dv_bias=None):
     a = L.SwinAttnArgs()
+    a.v_bias, a.dv_bias = L.ptr(v_bias), L.ptr(dv_bias)
     a.dtype = L.dtype_code(qkv.dtype)
     a.qkv, a.ctx, a.bias, a.logit_scale, a.lse = qkv.data_ptr(), ctx.data_ptr(), L.ptr(bias), logit_scale.data_ptr(), L.ptr(lse)
     a.bias_table = L.ptr(bias_table)
@@ -179,13 +180,13 @@ def _swin_args(qkv, ctx, bias, logit_scale, lse, B, R, w, shift, H, Cc, bias_tab
     return a
 
 
-def swin_attn_fwd(qkv, ctx, bias, logit_scale, lse=None, *, B, R, w, shift, H, C, bias_table=None, mfma=True):
+def swin_attn_fwd(qkv, ctx, bias, logit_scale, lse=None, *, B, R, w, shift, H, C, bias_table=None, mfma=True, v_bias=None):
     """bias [H, n, n] dense, or bias=None + bias_table [(2w-1)^2, H] (large windows: looked up per score); mfma=True hands the
     kernel the scratch its matrix-core form needs for windows of more than 64 tokens (False: the vector-ALU tiled kernel)"""
     import torch
     lib = L.load()
-    a = _swin_args(qkv, ctx, bias, logit_scale, lse, B, R, w, shift, H, C, bias_table)
-    if mfma and w * w > 64:
+    a = _swin_args(qkv, ctx, bias, logit_scale, lse, B, R, w, shift, H, C, bias_table, v_bias)
+    if mfma and (w * w > 64 or R % w):
         nbytes = lib.klab_swin_attn_bwd_ws_bytes(a.dtype, B, R, w, H, C)
         if nbytes:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=qkv.device)
@@ -194,11 +195,11 @@ def swin_attn_fwd(qkv, ctx, bias, logit_scale, lse=None, *, B, R, w, shift, H, C
 
 
 def swin_attn_bwd(qkv, ctx, bias, logit_scale, lse, dctx, dqkv, dbias=None, dlogit_scale=None, *, B, R, w, shift, H, C, mfma=True,
-                  bias_table=None, dbias_table=None):
+                  bias_table=None, dbias_table=None, v_bias=None, dv_bias=None):
     """mfma=True hands the kernel its scratch (when the shape is inside the matrix-core envelope); False forces the VALU form."""
     import torch
     lib = L.load()
-    a = _swin_args(qkv, ctx, bias, logit_scale, lse, B, R, w, shift, H, C, bias_table)
+    a = _swin_args(qkv, ctx, bias, logit_scale, lse, B, R, w, shift, H, C, bias_table, v_bias, dv_bias)
     a.dbias_table = L.ptr(dbias_table)
     a.dctx, a.dqkv, a.dbias, a.dlogit_scale = dctx.data_ptr(), dqkv.data_ptr(), L.ptr(dbias), L.ptr(dlogit_scale)
     nbytes = lib.klab_swin_attn_bwd_ws_bytes(a.dtype, B, R, w, H, C) if mfma else 0

@@ -187,18 +187,25 @@ def swin_block(sd: SD, prefix: str, x: Tensor, R: int, heads: int, w: int, shift
                eps: float) -> Tensor:
     """Swinv2Layer.forward, eval mode (HF/swinv2:652-705); res-post-norm."""
     B, T, C = x.shape
-    assert R % w == 0, "padding path (HF/swinv2:645-650) is outside the scoped configs"
     shortcut = x
     h = x.view(B, R, R, C)
+    # pad to a multiple of the window on the right / bottom with ZERO rows (maybe_pad, HF/swinv2:645-650): the padded tokens
+    # go through the attention like any other (k = 0, v = value bias) and are cropped afterwards (HF/swinv2:688-690)
+    pad = (w - R % w) % w
+    Rp = R + pad
+    if pad:
+        h = F.pad(h, (0, 0, 0, pad, 0, pad))
     if shift > 0:
         h = torch.roll(h, shifts=(-shift, -shift), dims=(1, 2))
     xw = _window_partition(h, w).view(-1, w * w, C)
-    mask = swin_shift_mask(R, w, shift, x.dtype)
+    mask = swin_shift_mask(Rp, w, shift, x.dtype)  # regions of the PADDED grid (HF/swinv2:675)
     ctx = swin_window_attention(sd, prefix + "attention.self.", xw, heads, w, pretrained_w, mask)
     ao = F.linear(ctx, sd[prefix + "attention.output.dense.weight"], sd[prefix + "attention.output.dense.bias"])
-    h = _window_reverse(ao.view(-1, w, w, C), w, R, R)
+    h = _window_reverse(ao.view(-1, w, w, C), w, Rp, Rp)
     if shift > 0:
         h = torch.roll(h, shifts=(shift, shift), dims=(1, 2))
+    if pad:
+        h = h[:, :R, :R, :].contiguous()
     h = h.view(B, T, C)
     h = F.layer_norm(h, (C,), sd[prefix + "layernorm_before.weight"], sd[prefix + "layernorm_before.bias"], eps)
     x = shortcut + h

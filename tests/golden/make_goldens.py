@@ -46,6 +46,21 @@ CONFIGS = {
                 num_decoder_layers=3),
         B=2, Ls=20, Lt=40, pad_tail=True, seed=23,
     ),
+    # window PADDING (HF/swinv2:645-650, 688-690): 80 px / patch 4 -> 20x20 tokens with window 6 -> padded to 24x24 (16 windows,
+    # shift 3), then 10x10 -> padded to 12x12; padded tokens are zero rows that still act as keys (k = 0, v = value bias).
+    "tiny_c": dict(
+        swin=dict(image_size=80, patch_size=4, embed_dim=32, depths=[2, 2], num_heads=[1, 2], window_size=6),
+        t5=dict(vocab_size=256, d_model=64, d_kv=32, num_heads=2, d_ff=128, num_layers=2, num_decoder_layers=2),
+        B=2, Ls=6, Lt=9, pad_tail=True, seed=31,
+    ),
+    # padding together with windows of more than 64 tokens: 96 px -> 24x24 tokens, window 10 (n = 100) -> padded to 30x30 (shift
+    # 5), then 12x12 -> padded to 20x20; pretrained_window_sizes set (log-spaced coordinate table normalised by them)
+    "tiny_d": dict(
+        swin=dict(image_size=96, patch_size=4, embed_dim=32, depths=[2, 2], num_heads=[1, 2], window_size=10,
+                  pretrained_window_sizes=[5, 5]),
+        t5=dict(vocab_size=256, d_model=64, d_kv=32, num_heads=2, d_ff=128, num_layers=2, num_decoder_layers=2),
+        B=2, Ls=6, Lt=9, pad_tail=True, seed=41,
+    ),
 }
 
 

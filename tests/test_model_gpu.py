@@ -36,7 +36,7 @@ def run(m, g):
     return m(images, src, tgt)
 
 
-@pytest.mark.parametrize("name", ["tiny_a", "tiny_b"])
+@pytest.mark.parametrize("name", ["tiny_a", "tiny_b", "tiny_c", "tiny_d"])  # c, d: padded windows (HF/swinv2:645-650), d with 100-token windows
 @pytest.mark.parametrize("train_swin", [False, True])
 def test_fp32_engine_matches_reference(name, train_swin):
     m, g = build(name, torch.float32, train_swin)
@@ -72,7 +72,7 @@ def test_fp32_engine_matches_reference(name, train_swin):
     print(name, train_swin, "loss", loss.item(), "worst grad", worst)
 
 
-@pytest.mark.parametrize("name", ["tiny_a", "tiny_b"])
+@pytest.mark.parametrize("name", ["tiny_a", "tiny_b", "tiny_c", "tiny_d"])
 def test_bf16_engine_within_stated_tolerance(name):
     m, g = build(name, torch.bfloat16, True)
     m.transformer.eval()

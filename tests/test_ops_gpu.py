@@ -504,6 +504,50 @@ def test_swin_large_window_attention_fwd_bwd(ops, dt, B, R, w, shift, H, C):
         assert rel_l2(dls.cpu(), lr.grad) < t * 10, form
 
 
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("B,R,w,shift,H,C", [(1, 20, 6, 3, 2, 64), (2, 10, 6, 0, 1, 32), (1, 24, 10, 5, 1, 32), (2, 9, 4, 2, 2, 64)])
+def test_swin_padded_window_attention_fwd_bwd(ops, dt, B, R, w, shift, H, C):
+    """window PADDING (R % w != 0; HF/swinv2:645-650, 675, 688-690): the grid is padded to ceil(R/w)*w with zero input rows that
+    still act as keys (k = 0, v = value bias), the shift mask is built on the padded grid, the output is cropped.  Reference = the
+    dense-bias window attention on the explicitly padded grid; checked: output, d qkv, d(bias table), d logit_scale, d(value bias)."""
+    n, ntab = w * w, (2 * w - 1) ** 2
+    Rp = (R + w - 1) // w * w
+    _coords, index = O.swin_coords_table_and_index(w, 0, torch.float32)
+    qkv = rnd(B * R * R, 3 * C, seed=1).to(dt)
+    btab = 16 * torch.sigmoid(rnd(ntab, H, seed=2))
+    ls = torch.log(10 * torch.ones(H)) + 0.3 * rnd(H, seed=3)
+    vbias = rnd(C, seed=5, scale=0.5)
+    dctx = rnd(B * R * R, C, seed=4).to(dt)
+    qr = qkv.float().clone().requires_grad_(True)
+    tr, lr, vr = btab.clone().requires_grad_(True), ls.clone().requires_grad_(True), vbias.clone().requires_grad_(True)
+    xp = F.pad(qr.view(B, R, R, 3 * C), (0, 0, 0, Rp - R, 0, Rp - R))
+    padmask = torch.ones(Rp, Rp)
+    padmask[:R, :R] = 0
+    vb_full = torch.cat([torch.zeros(2 * C), vr if dt == torch.float32 else vr.detach().to(dt).float() + (vr - vr.detach())])  # bf16: the kernel's rounding, straight-through gradient
+    xp = xp + padmask[None, :, :, None] * vb_full
+    ref = _swin_attn_ref(xp.reshape(B * Rp * Rp, 3 * C), _table_to_dense(tr, index, H, n), lr, B, Rp, w, shift, H, C)
+    ref = ref.view(B, Rp, Rp, C)[:, :R, :R].reshape(B * R * R, C)
+    ref.backward(dctx.float())
+    nW = (Rp // w) ** 2
+    kw = dict(B=B, R=R, w=w, shift=shift, H=H, C=C)
+    t = tol(dt) * 4
+    forms = ("mfma", "valu") if (dt == torch.bfloat16 and C == H * 32) else ("valu",)
+    for form in forms:
+        mf = form == "mfma"
+        ctx = torch.zeros(B * R * R, C, device="cuda", dtype=dt)
+        lse = torch.zeros(B * nW * H * n, device="cuda")
+        dqkv = torch.zeros(B * R * R, 3 * C, device="cuda", dtype=dt)
+        dls, dtab, dvb = torch.zeros(H, device="cuda"), torch.zeros(ntab, H, device="cuda"), torch.zeros(C, device="cuda")
+        ops.swin_attn_fwd(dev(qkv), ctx, None, dev(ls), lse, bias_table=dev(btab), v_bias=dev(vbias), mfma=mf, **kw)
+        assert rel_l2(ctx.float().cpu(), ref.detach()) < tol(dt), form
+        ops.swin_attn_bwd(dev(qkv), ctx, None, dev(ls), lse, dev(dctx), dqkv, None, dls, bias_table=dev(btab), dbias_table=dtab,
+                          v_bias=dev(vbias), dv_bias=dvb, mfma=mf, **kw)
+        assert rel_l2(dqkv.float().cpu(), qr.grad) < t, form
+        assert rel_l2(dtab.cpu(), tr.grad) < t, form
+        assert rel_l2(dls.cpu(), lr.grad) < t * 10, form
+        assert rel_l2(dvb.cpu(), vr.grad) < t, form
+
+
 @pytest.mark.parametrize("w,pw,H", [(12, 6, 4), (24, 12, 2), (8, 0, 3)])
 def test_swin_cpb_table_fwd_bwd(ops, w, pw, H):
     """table form of the continuous position bias (any window size; HF/swinv2:376-378,418-428,457-492): 16*sigmoid(MLP(coords))

@@ -6,7 +6,7 @@ from oracle import swin_t5_oracle as O
 from tests.helpers import load_golden, rel_l2
 
 
-@pytest.mark.parametrize("name", ["tiny_a", "tiny_b"])
+@pytest.mark.parametrize("name", ["tiny_a", "tiny_b", "tiny_c", "tiny_d"])  # c, d: window padding (HF/swinv2:645-650), d with n = 100
 def test_oracle_matches_reference_loss_acts_grads(name):
     g = load_golden(name)
     sds = {m: {k: v.clone().requires_grad_(v.is_floating_point() and m != "lang") for k, v in sd.items()}
