@@ -177,6 +177,7 @@ class DistributedDataParallel(nn.Module):
             eng.set_bucket_events(dist.is_initialized())
         module._direct_grads = True
         module._segment_hook = self._on_segment
+        module._reducer = self.reducer
         self.overlap_optimizer = bool(overlap_optimizer)
         module._pending_reduce = None
         if broadcast_parameters and dist.is_initialized() and dist.get_world_size(process_group) > 1:

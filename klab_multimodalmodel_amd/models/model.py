@@ -154,6 +154,9 @@ class _LossFn(torch.autograd.Function):
                 if state.get(seg_model[seg]) == "fresh":
                     if model._segment_hook is not None:
                         model._segment_hook(seg)
+                    opt = model._optimizer_in_backward() if model._optimizer_in_backward is not None else None
+                    if opt is not None and seg_model[seg] == "main":
+                        opt._segment_ready(model, seg)  # optim.FusedAdam(step_in_backward=True)
                     if last_of_model:
                         settle(seg_model[seg])
                 elif last_of_model:
@@ -212,6 +215,9 @@ class MyModel(nn.Module):
         self._views = None
         self._direct_grads = False
         self._segment_hook = None
+        self._optimizer_in_backward = None  # weakref to an optim.FusedAdam(step_in_backward=True) after its first fused step
+        self._pending_opt_stream = None  # stream of an in-backward optimizer update that step() has not joined yet
+        self._reducer = None  # klab DDP's SegmentReducer
         self._pending_reduce = None  # klab DDP(overlap_optimizer=True): reducer whose last all-reduces are not joined yet
         self.use_graph = os.environ.get("KLAB_GRAPH", "0") == "1"  # hipGraph replay of the engine's launch sequences
         self._seed_base = torch.initial_seed() & 0xFFFFFFFF
@@ -331,6 +337,9 @@ class MyModel(nn.Module):
 
     # ---- the reference surface -----------------------------------------------------------------
     def forward(self, images, source_encoding, target_encoding=None, return_loss=True):
+        if self._pending_opt_stream is not None:  # an in-backward optimizer update nobody joined through step()
+            torch.cuda.current_stream().wait_stream(self._pending_opt_stream)
+            self._pending_opt_stream = None
         if self._pending_reduce is not None:  # nobody consumed the last backward's gradients through FusedAdam: join now
             red, self._pending_reduce = self._pending_reduce, None
             red.finish()

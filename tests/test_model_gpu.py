@@ -191,7 +191,7 @@ def _drop_engines():
     torch.cuda.synchronize()
 
 
-def _train_steps(wrap, accumulate=1, steps=3, fused_adam=False, overlap=False):
+def _train_steps(wrap, accumulate=1, steps=3, fused_adam=False, overlap=False, in_backward=False):
     """the reference's loop body (ref/train.py:58-71) on a tiny config; returns losses and final weights."""
     import torch.distributed as dist
     m, g = build("tiny_b", torch.float32, True)
@@ -207,7 +207,7 @@ def _train_steps(wrap, accumulate=1, steps=3, fused_adam=False, overlap=False):
         model = core = m
     if fused_adam:
         from klab_multimodalmodel_amd.optim import FusedAdam
-        opt = FusedAdam(core.transformer.parameters(), lr=1e-3)
+        opt = FusedAdam(core.transformer.parameters(), lr=1e-3, step_in_backward=in_backward)
     else:
         opt = torch.optim.Adam(core.transformer.parameters(), lr=1e-3)
     losses = []
@@ -220,6 +220,8 @@ def _train_steps(wrap, accumulate=1, steps=3, fused_adam=False, overlap=False):
                 model.join()  # a consumer other than FusedAdam has to join the pending all-reduces itself
             opt.step()
             opt.zero_grad()
+    if in_backward:  # every step but the first updated segment 0 underneath the encoder's backward
+        assert opt._fallback is None and opt.in_backward_updates == steps - 1, (opt._fb_reason, opt.in_backward_updates)
     w = {k: v.detach().clone() for k, v in core.transformer.state_dict().items()}
     sg = core.image_model.get_parameter("layernorm.weight").grad
     sg = None if sg is None else sg.detach().clone()
@@ -247,6 +249,12 @@ def test_reference_training_loop_under_stock_ddp_and_klab_ddp():
                 # overlap_optimizer: backward leaves the last all-reduces unjoined, FusedAdam updates segment by segment
                 l5, w5, _s5 = _train_steps("klab", acc, fused_adam=True, overlap=True)
                 l6, w6, _s6 = _train_steps("klab", acc, fused_adam=False, overlap=True)  # torch Adam behind an explicit ddp.join()
+                if acc == 1:  # FusedAdam(step_in_backward=True): segment 0 updated behind ITS all-reduce, underneath the encoder backward
+                    for ov in (False, True):
+                        l7, w7, _s7 = _train_steps("klab", acc, fused_adam=True, overlap=ov, in_backward=True)
+                        assert max(abs(x - y) for x, y in zip(l0, l7)) < 2e-4, (ov, l0, l7)
+                        for k in w0:
+                            assert rel_l2(w7[k].cpu(), w0[k].cpu()) < 2e-3, (ov, k)
             finally:
                 del os.environ["KLAB_DDP_FORCE_COLLECTIVE"]
             assert max(abs(x - y) for x, y in zip(l0, l4)) < 2e-4, (acc, l0, l4)
@@ -450,6 +458,46 @@ def test_fused_adam_matches_torch_adam(dtype, wd):
     k0 = next(iter(sd["state"]))
     assert set(sd["state"][k0].keys()) >= {"step", "exp_avg", "exp_avg_sq"}
     assert rel_l2(sd["state"][k0]["exp_avg"].cpu(), ref_sd["state"][k0]["exp_avg"].cpu()) < (1e-4 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_adam_step_in_backward(dtype):
+    """optim.FusedAdam(step_in_backward=True): the update of backward segment 0 runs on a side stream underneath the encoder's
+    backward, segment 1 at step().  Same arithmetic as the one-kernel step: same weights and Adam state after 5 steps, with
+    dropout ON (the mask stream is a function of the step count only), and a forward that nobody followed with step() joins."""
+    from klab_multimodalmodel_amd.optim import FusedAdam
+    ms, opts = [], []
+    for inb in (False, True):
+        m, g = build("tiny_b", dtype, False)
+        m._direct_grads = True
+        m.transformer.train()
+        opts.append(FusedAdam(m.transformer.parameters(), lr=2e-3, weight_decay=0.01, step_in_backward=inb))
+        ms.append(m)
+    for step in range(5):
+        ls = []
+        for k in (0, 1):
+            loss = run(ms[k], g)
+            loss.backward()
+            opts[k].step()
+            opts[k].zero_grad()
+            ls.append(float(loss))
+        assert abs(ls[0] - ls[1]) <= (2e-5 if dtype == torch.float32 else 3e-3) * abs(ls[0]) + 1e-6, (step, ls)
+    assert opts[1]._fallback is None and opts[1].in_backward_updates == 4 and opts[0].in_backward_updates == 0
+    assert ms[1]._trainable_current()
+    worst = 0.0
+    for (n0, p0), (_n1, p1) in zip(ms[0].transformer.named_parameters(), ms[1].transformer.named_parameters()):
+        worst = max(worst, rel_l2(p1.detach().cpu(), p0.detach().cpu()))
+    assert worst < (1e-5 if dtype == torch.float32 else 2e-2), worst
+    assert rel_l2(opts[1]._m.cpu(), opts[0]._m.cpu()) < (1e-4 if dtype == torch.float32 else 3e-2)
+    assert rel_l2(opts[1]._v.cpu(), opts[0]._v.cpu()) < (1e-4 if dtype == torch.float32 else 3e-2)
+    # a backward whose step() never comes: the next forward still orders itself behind the in-flight segment-0 update
+    run(ms[1], g).backward()
+    assert ms[1]._pending_opt_stream is not None
+    with torch.no_grad():
+        run(ms[1], g)
+    assert ms[1]._pending_opt_stream is None
+    torch.cuda.synchronize()
 
 
 @pytest.mark.gpu
