@@ -214,6 +214,37 @@ int klab_image_preprocess(const unsigned char* src, const klab_image_desc* desc_
                           int out_size, int filter_a, int filter_b, double rescale, const float* mean3, const float* std3,
                           float* pixel_values, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- JPEG decoding (row f-1: `Image.open(path).convert('RGB')`, ref/modules/loader.py:15) -------------------------------
+ * Hybrid decoder for baseline / extended-sequential 8-bit Huffman JPEG (SOF0 / SOF1; grey, or three components with 4:4:4, 4:2:2
+ * or 4:2:0 sampling; restart intervals; one interleaved scan).  The serial part -- marker parsing and Huffman
+ * decoding -- runs on the host (`klab_jpeg_entropy_decode*`, threaded over the images of a batch) and yields quantised DCT
+ * coefficients; dequantisation, the inverse DCT, chroma upsampling and the colour transform run on the GPU
+ * (`klab_jpeg_decode_device`) and write HWC uint8 RGB at the offsets `klab_image_preprocess` reads.  Output is bit-identical to
+ * Pillow's decode (libjpeg-turbo defaults: integer "islow" IDCT, triangle-filter upsampling, 16-bit colour tables).
+ * Progressive / arithmetic / lossless / 12-bit / CMYK / multi-scan files: KLAB_ERR_UNSUPPORTED (`supported` = 0 in klab_jpeg_info).
+ *   coefs:  int16, 64 per block in natural (row-major) order; per image the blocks of component 0, then 1, then 2, each as
+ *           [bh][bw] over the MCU-padded block grid; qt: uint16 [3][64] per image (natural order, one table per component).   */
+#define KLAB_JPEG_GRAY 0
+#define KLAB_JPEG_YCC 1
+#define KLAB_JPEG_RGB 2
+typedef struct klab_jpeg_info {
+  int width, height, ncomp, precision, progressive, supported, colour;
+  int hmax, vmax, mcus_x, mcus_y;
+  int hs[3], vs[3], bw[3], bh[3], tq[3];
+  long long coef_blocks; /* sum of bw*bh over the components */
+} klab_jpeg_info;
+typedef struct klab_jpeg_item { klab_jpeg_info info; long long coef_block0; long long rgb_off; } klab_jpeg_item;
+int klab_jpeg_read_info(const unsigned char* data, size_t n, klab_jpeg_info* info);                       /* host, header only */
+int klab_jpeg_entropy_decode(const unsigned char* data, size_t n, short* coefs, unsigned short* qt, klab_jpeg_info* info); /* host */
+/* host, n_threads workers; coefs[i] -> room for infos[i].coef_blocks*64 shorts; qt: [n][3][64]; rcs[i]: per-image status      */
+int klab_jpeg_entropy_decode_batch(const unsigned char* const* data, const size_t* sizes, int n, short* const* coefs,
+                                   unsigned short* qt, klab_jpeg_info* infos, int* rcs, int n_threads);
+/* device: items (host copy, validated and used to size the grids) / items_dev (the same bytes on the device): per image the
+ * header info, the first coefficient block in coefs_dev and the byte offset of its RGB image in rgb_dev                        */
+size_t klab_jpeg_decode_ws_bytes(const klab_jpeg_item* items, int n);
+int klab_jpeg_decode_device(const short* coefs_dev, const unsigned short* qt_dev, const klab_jpeg_item* items,
+                            const klab_jpeg_item* items_dev, int n, unsigned char* rgb_dev, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- glue --------------------------------------------------------------------------------- */
 /* multi-tensor f32 -> dtype cast into one arena; desc_dev: device array of
  * {const float* src; long dst_off; long n4_prefix} (prefix sums of element counts / 4)           */

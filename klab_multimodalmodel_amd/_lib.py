@@ -92,7 +92,22 @@ SIGNATURES = {
     "klab_segv_trace_install": [i32],
     "klab_segv_set_context": [C.c_char_p],
     "klab_image_preprocess": [vp, vp, i32, i32, i32, i32, i32, i32, i32, C.c_double, vp, vp, vp, vp, C.c_size_t, vp],
+    "klab_jpeg_read_info": [vp, C.c_size_t, vp],
+    "klab_jpeg_entropy_decode": [vp, C.c_size_t, vp, vp, vp],
+    "klab_jpeg_entropy_decode_batch": [vp, vp, i32, vp, vp, vp, vp, i32],
+    "klab_jpeg_decode_ws_bytes": [vp, i32],
+    "klab_jpeg_decode_device": [vp, vp, vp, vp, i32, vp, vp, C.c_size_t, vp],
 }
+
+
+class JpegInfo(C.Structure):  # klab_jpeg_info
+    _fields_ = [("width", i32), ("height", i32), ("ncomp", i32), ("precision", i32), ("progressive", i32), ("supported", i32),
+                ("colour", i32), ("hmax", i32), ("vmax", i32), ("mcus_x", i32), ("mcus_y", i32), ("hs", i32 * 3), ("vs", i32 * 3),
+                ("bw", i32 * 3), ("bh", i32 * 3), ("tq", i32 * 3), ("coef_blocks", C.c_longlong)]
+
+
+class JpegItem(C.Structure):  # klab_jpeg_item
+    _fields_ = [("info", JpegInfo), ("coef_block0", C.c_longlong), ("rgb_off", C.c_longlong)]
 
 _lib = None
 

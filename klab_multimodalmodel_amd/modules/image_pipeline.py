@@ -3,14 +3,18 @@
 Reference (main process, one image at a time):
     ref/modules/loader.py:15-16   Image.open(path).convert('RGB').resize((256, 256)) ; ToTensor()
     ref/train.py:55               images = image_processor(images, return_tensors="pt").to(device_id)
-Here JPEG decoding stays with PIL (no decoder on the device); everything after it -- both Pillow resizes, the float
-conversion, the processor's rescale (twice, as the reference effectively does) and normalisation -- runs on the GPU and is
-bit-identical to Pillow at every uint8 stage (`csrc/image_pre.hip`).  Two entry points:
+Everything after the file read runs on the GPU and is bit-identical to Pillow at every uint8 stage: JPEG reconstruction
+(`csrc/jpeg.hip`: dequantisation, inverse DCT, chroma upsampling, colour transform; only the serial Huffman decoding stays on the
+host, in C++ threads, `csrc/jpeg_host.cpp`), both Pillow resizes, the float conversion, the processor's rescale (twice, as the
+reference effectively does) and normalisation (`csrc/image_pre.hip`).  Entry points:
 
     GpuImageProcessor()(images)                 drop-in for `image_processor(images, return_tensors="pt")`: `images` is the
                                                 DataLoader's [B, 3, 256, 256] float batch in [0, 1] (or a list of such CHW tensors)
     GpuImageProcessor().from_decoded(arrays)    list of decoded HWC uint8 RGB images of ANY size (numpy / PIL.Image / tensor):
                                                 replaces loader.py:15-16 as well (use `DatasetLoader(decode_only=True)`)
+    GpuImageProcessor().from_jpeg(files)        list of JPEG files (paths or bytes): replaces `Image.open(path).convert('RGB')` too.
+                                                Baseline / extended-sequential files; a progressive, CMYK or multi-scan file raises
+                                                NotImplementedError (decode that one with PIL and pass it to from_decoded)
 
 Both return {"pixel_values": cuda float32 [B, 3, 224, 224]} -- what `MyModel.forward` takes.  No CPU fallback: without the HIP
 library the call raises.
@@ -141,6 +145,26 @@ class GpuImageProcessor:
         dd = torch.from_numpy(desc).to(self.device)
         pv = self._out(n)
         ops.image_preprocess(src, dd, n, max(a.shape[0] for a in arrs), max(a.shape[1] for a in arrs), pv, mid=self.loader_size,
+                             out=self.size, filter_a=self.loader_resample, filter_b=self.resample, rescale=self.rescale, mean=self.mean,
+                             std=self.std)
+        return BatchFeature(pixel_values=pv)
+
+    def from_jpeg(self, files, n_threads=8):
+        """list of JPEG files (paths, bytes or binary file objects) -> pixel_values; `Image.open(f).convert('RGB')` + from_decoded"""
+        datas = []
+        for f in files:
+            if isinstance(f, (bytes, bytearray, memoryview)):
+                datas.append(bytes(f))
+            elif hasattr(f, "read"):
+                datas.append(f.read())
+            else:
+                with open(f, "rb") as fh:
+                    datas.append(fh.read())
+        coefs_t, qt, items, rgb_bytes = ops.jpeg_entropy_decode_batch(datas, n_threads)
+        rgb, desc = ops.jpeg_decode_device(coefs_t, qt, items, rgb_bytes, self.device)
+        n = len(datas)
+        pv = self._out(n)
+        ops.image_preprocess(rgb, desc, n, max(it.info.height for it in items), max(it.info.width for it in items), pv, mid=self.loader_size,
                              out=self.size, filter_a=self.loader_resample, filter_b=self.resample, rescale=self.rescale, mean=self.mean,
                              std=self.std)
         return BatchFeature(pixel_values=pv)

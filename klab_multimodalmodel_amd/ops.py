@@ -314,3 +314,88 @@ def image_preprocess(src_u8, desc, n, max_h, max_w, pixel_values, *, mid=256, ou
     L.check(lib.klab_image_preprocess(src_u8.data_ptr(), L.ptr(desc), n, max_h, max_w, mid, out, filter_a, filter_b, rescale,
                                       C.cast(m3, C.c_void_p), C.cast(s3, C.c_void_p), pixel_values.data_ptr(), L.ptr(ws), nbytes,
                                       L.stream_ptr()), "klab_image_preprocess")
+
+
+# ---- JPEG (row f-1): host entropy decoding + device reconstruction ---------------------------------------------------------
+def jpeg_read_info(data: bytes):
+    """header of one JPEG file (host only): a _lib.JpegInfo"""
+    lib = L.load()
+    info = L.JpegInfo()
+    buf = (C.c_ubyte * len(data)).from_buffer_copy(data)
+    L.check(lib.klab_jpeg_read_info(C.cast(buf, C.c_void_p), len(data), C.byref(info)), "klab_jpeg_read_info")
+    return info
+
+
+def jpeg_entropy_decode_batch(datas, n_threads=8):
+    """Huffman-decode a list of JPEG byte strings on the host (threaded).  Returns (coefs int16 numpy [total_blocks, 64] in pinned
+    memory when CUDA is available, qt uint16 numpy [n, 3, 64], items = (_lib.JpegItem * n) with coef_block0 filled, rgb_off = byte
+    offsets of 16-byte aligned HWC RGB images, total RGB bytes).  Unsupported files (progressive, CMYK, ...) raise
+    NotImplementedError naming the index."""
+    import numpy as np
+    import torch
+    lib = L.load()
+    n = len(datas)
+    items = (L.JpegItem * n)()
+    bufs = [(C.c_ubyte * len(d)).from_buffer_copy(d) for d in datas]
+    blocks, rgb = 0, 0
+    for i, d in enumerate(datas):
+        L.check(lib.klab_jpeg_read_info(C.cast(bufs[i], C.c_void_p), len(d), C.byref(items[i].info)), f"klab_jpeg_read_info[{i}]")
+        f = items[i].info
+        if not f.supported:
+            raise NotImplementedError(f"klab: JPEG {i} is outside the device decoder (progressive={f.progressive}, components={f.ncomp}, "
+                                      f"precision={f.precision}, sampling={list(f.hs)}x{list(f.vs)})")
+        items[i].coef_block0 = blocks
+        items[i].rgb_off = rgb
+        blocks += f.coef_blocks
+        rgb += (f.width * f.height * 3 + 15) // 16 * 16
+    coefs_t = torch.empty((max(blocks, 1), 64), dtype=torch.int16, pin_memory=torch.cuda.is_available())
+    coefs = coefs_t.numpy()
+    qt = np.zeros((n, 3, 64), np.uint16)
+    ptrs = (C.c_void_p * n)(*[C.cast(b, C.c_void_p) for b in bufs])
+    sizes = (C.c_size_t * n)(*[len(d) for d in datas])
+    cps = (C.c_void_p * n)(*[coefs.ctypes.data + items[i].coef_block0 * 128 for i in range(n)])
+    infos = (L.JpegInfo * n)()
+    rcs = (C.c_int * n)()
+    rc = lib.klab_jpeg_entropy_decode_batch(C.cast(ptrs, C.c_void_p), C.cast(sizes, C.c_void_p), n, C.cast(cps, C.c_void_p),
+                                            qt.ctypes.data, C.cast(infos, C.c_void_p), C.cast(rcs, C.c_void_p), int(n_threads))
+    if rc:
+        bad = [i for i in range(n) if rcs[i]]
+        L.check(rcs[bad[0]] if bad else rc, f"klab_jpeg_entropy_decode_batch (images {bad})")
+    return coefs_t, qt, items, rgb
+
+
+def jpeg_decode_device(coefs_t, qt, items, rgb_bytes, device="cuda"):
+    """device half: returns (rgb uint8 device buffer holding the HWC images at items[i].rgb_off, desc int64 [n, 2] device tensor in
+    the klab_image_desc layout that image_preprocess takes)"""
+    import numpy as np
+    import torch
+    lib = L.load()
+    n = len(items)
+    dev = torch.device(device)
+    coefs_dev = coefs_t.to(dev, non_blocking=True)
+    qt_dev = torch.from_numpy(qt.view(np.int16)).to(dev)
+    raw = np.frombuffer(bytes(items), dtype=np.uint8).copy()
+    items_dev = torch.from_numpy(raw).to(dev)
+    nbytes = lib.klab_jpeg_decode_ws_bytes(C.cast(items, C.c_void_p), n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    rgb = torch.empty(max(rgb_bytes, 16), dtype=torch.uint8, device=dev)
+    L.check(lib.klab_jpeg_decode_device(coefs_dev.data_ptr(), qt_dev.data_ptr(), C.cast(items, C.c_void_p), items_dev.data_ptr(), n,
+                                        rgb.data_ptr(), ws.data_ptr(), nbytes, L.stream_ptr()), "klab_jpeg_decode_device")
+    desc = np.zeros((n, 2), np.int64)
+    for i in range(n):
+        desc[i, 0] = items[i].rgb_off
+        desc[i, 1] = items[i].info.height | (items[i].info.width << 32)
+    # (coefs_dev / qt_dev / items_dev / ws are consumed by kernels already enqueued on the current stream; the caching allocator
+    # keeps their memory ordered behind that stream)
+    return rgb, torch.from_numpy(desc).to(dev)
+
+
+def jpeg_decode(datas, device="cuda", n_threads=8):
+    """list of JPEG byte strings -> list of HWC uint8 RGB device tensors (views into one buffer): `Image.open(f).convert('RGB')`"""
+    coefs_t, qt, items, rgb_bytes = jpeg_entropy_decode_batch(datas, n_threads)
+    rgb, _desc = jpeg_decode_device(coefs_t, qt, items, rgb_bytes, device)
+    out = []
+    for it in items:
+        h, w = it.info.height, it.info.width
+        out.append(rgb[it.rgb_off:it.rgb_off + h * w * 3].view(h, w, 3))
+    return out

@@ -39,11 +39,39 @@ SHAPES = [  # name, M, N, K, a_kmajor, b_kmajor, atomic
 ]
 
 
+LARGE = [  # BASELINE configs[4] (T5-large d=1024, ff=4096, inner=1024; encoder 32 x 153 tokens, decoder 32 x 64)
+    ("L enc qkv fwd", 4896, 3072, 1024, True, True, False),
+    ("L enc o fwd", 4896, 1024, 1024, True, True, False),
+    ("L enc wi fwd", 4896, 4096, 1024, True, True, False),
+    ("L enc wo fwd", 4896, 1024, 4096, True, True, False),
+    ("L enc qkv dgrad", 4896, 1024, 3072, True, False, False),
+    ("L enc o dgrad", 4896, 1024, 1024, True, False, False),
+    ("L enc wi dgrad", 4896, 1024, 4096, True, False, False),
+    ("L enc wo dgrad", 4896, 4096, 1024, True, False, False),
+    ("L dec wi fwd", 2048, 4096, 1024, True, True, False),
+    ("L dec wi dgrad", 2048, 1024, 4096, True, False, False),
+    ("L dec wo dgrad", 2048, 4096, 1024, True, False, False),
+    ("L enc wi wgrad", 4096, 1024, 4896, False, False, True),
+    ("L enc wo wgrad", 1024, 4096, 4896, False, False, True),
+    ("L swin0 qkv fwd", 294912, 384, 128, True, True, False),
+    ("L swin0 qkv dgrad", 294912, 128, 384, True, False, False),
+    ("L swin0 fc1 fwd", 294912, 512, 128, True, True, False),
+    ("L swin0 fc2 dgrad", 294912, 512, 128, True, False, False),
+    ("L swin2 qkv fwd", 18432, 1536, 512, True, True, False),
+    ("L swin2 fc1 fwd", 18432, 2048, 512, True, True, False),
+    ("L swin2 fc1 dgrad", 18432, 512, 2048, True, False, False),
+    ("L swin2 fc2 dgrad", 18432, 2048, 512, True, False, False),
+]
+
+
 def main():
     dt = torch.bfloat16
     tot = 0.0
     flt = sys.argv[1:]
-    for name, M, N, K, ak, bk, atomic in SHAPES:
+    shapes = SHAPES
+    if flt and flt[0] == "--large":
+        shapes, flt = LARGE, flt[1:]
+    for name, M, N, K, ak, bk, atomic in shapes:
         if flt and not any(f in name for f in flt):
             continue
         A = torch.randn((M, K) if ak else (K, M), device="cuda").to(dt)
