@@ -48,12 +48,18 @@ class DatasetLoader(torch.utils.data.Dataset):
     # 256x256 resize, ToTensor and the image processor then run on the GPU (`modules.image_pipeline.GpuImageProcessor
     # .from_decoded`, bit-identical to Pillow).  Batches of such items need `collate_decoded` (images stay a list).
     decode_only = False
+    # file_bytes (klab extension): __getitem__ returns the JPEG file's bytes; decoding too then runs through
+    # `GpuImageProcessor.from_jpeg` (host Huffman stage + device reconstruction, byte-identical to `Image.open().convert('RGB')`)
+    file_bytes = False
 
     def __init__(self):
         self.images, self.tgt_texts, self.src_texts = [], [], []
         self.transform = pil_to_tensor01
 
     def _load_image(self, path):
+        if self.file_bytes:
+            with open(path, 'rb') as f:
+                return f.read()
         if self.decode_only:
             return torch.from_numpy(np.asarray(Image.open(path).convert('RGB'), dtype=np.uint8).copy())
         return self.transform(Image.open(path).convert('RGB').resize((256, 256)))
@@ -97,7 +103,8 @@ class RedCapsDatasetLoader(DatasetLoader):
 
 
 def collate_decoded(batch):
-    """collate_fn for `decode_only` datasets: (list of HWC uint8 tensors, list of src texts, list of tgt texts)"""
+    """collate_fn for `decode_only` / `file_bytes` datasets: (list of HWC uint8 tensors or of JPEG byte strings, list of src texts,
+    list of tgt texts)"""
     images, src, tgt = zip(*batch)
     return list(images), list(src), list(tgt)
 
@@ -115,5 +122,6 @@ def get_dataloader(args, phase, rank):
                                                               shuffle=True, drop_last=True)
     gpu_pre = bool(getattr(args, 'gpu_preprocess', False))  # klab extension; the reference has no such flag (default off)
     dataset.decode_only = gpu_pre
+    dataset.file_bytes = gpu_pre and bool(getattr(args, 'gpu_jpeg_decode', False))  # klab extension: batches carry file bytes
     return torch.utils.data.DataLoader(dataset, batch_size=args.batch_size, num_workers=os.cpu_count() // 4, pin_memory=not gpu_pre,
                                        sampler=sampler, collate_fn=collate_decoded if gpu_pre else None)

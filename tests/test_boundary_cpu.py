@@ -186,6 +186,19 @@ def test_dataset_item_matches_totensor_semantics(tmp_path):
     assert img.shape == (3, 256, 256) and img.dtype == torch.float32 and 0.0 <= float(img.min()) and float(img.max()) <= 1.0
     ref = torch.from_numpy(np.asarray(Image.fromarray(arr).convert("RGB").resize((256, 256))).transpose(2, 0, 1).copy()).float() / 255
     assert torch.equal(img, ref) and (s, t) == ("s", "t") and len(ds) == 1
+    # klab extensions: the decoded image at its own size / the file's bytes (for GpuImageProcessor.from_decoded / .from_jpeg)
+    from klab_multimodalmodel_amd.modules.loader import collate_decoded
+    Image.fromarray(arr).save(tmp_path / "y.jpg", quality=90)
+    ds.images = [str(tmp_path / "y.jpg")]
+    ds.decode_only = True
+    img, _s, _t = ds[0]
+    assert img.dtype == torch.uint8 and tuple(img.shape) == (12, 10, 3)
+    assert np.array_equal(img.numpy(), np.asarray(Image.open(tmp_path / "y.jpg").convert("RGB")))
+    ds.file_bytes = True
+    raw, _s, _t = ds[0]
+    assert isinstance(raw, bytes) and raw == (tmp_path / "y.jpg").read_bytes()
+    imgs, ss, ts = collate_decoded([ds[0], ds[0]])
+    assert imgs == [raw, raw] and ss == ["s", "s"] and ts == ["t", "t"]
 
 
 def test_host_tables_match_oracle():
