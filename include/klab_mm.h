@@ -215,13 +215,13 @@ int klab_image_preprocess(const unsigned char* src, const klab_image_desc* desc_
                           float* pixel_values, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- JPEG decoding (row f-1: `Image.open(path).convert('RGB')`, ref/modules/loader.py:15) -------------------------------
- * Hybrid decoder for baseline / extended-sequential 8-bit Huffman JPEG (SOF0 / SOF1; grey, or three components with 4:4:4, 4:2:2
- * or 4:2:0 sampling; restart intervals; one interleaved scan).  The serial part -- marker parsing and Huffman
+ * Hybrid decoder for baseline / extended-sequential / progressive 8-bit Huffman JPEG (SOF0 / SOF1 / SOF2; grey, or three
+ * components with 4:4:4, 4:2:2 or 4:2:0 sampling; restart intervals; sequential files: one interleaved scan).  The serial part -- marker parsing and Huffman
  * decoding -- runs on the host (`klab_jpeg_entropy_decode*`, threaded over the images of a batch) and yields quantised DCT
  * coefficients; dequantisation, the inverse DCT, chroma upsampling and the colour transform run on the GPU
  * (`klab_jpeg_decode_device`) and write HWC uint8 RGB at the offsets `klab_image_preprocess` reads.  Output is bit-identical to
  * Pillow's decode (libjpeg-turbo defaults: integer "islow" IDCT, triangle-filter upsampling, 16-bit colour tables).
- * Progressive / arithmetic / lossless / 12-bit / CMYK / multi-scan files: KLAB_ERR_UNSUPPORTED (`supported` = 0 in klab_jpeg_info).
+ * Arithmetic-coded / lossless / 12-bit / CMYK / multi-scan sequential files: KLAB_ERR_UNSUPPORTED (`supported` = 0 in klab_jpeg_info).
  *   coefs:  int16, 64 per block in natural (row-major) order; per image the blocks of component 0, then 1, then 2, each as
  *           [bh][bw] over the MCU-padded block grid; qt: uint16 [3][64] per image (natural order, one table per component).   */
 #define KLAB_JPEG_GRAY 0

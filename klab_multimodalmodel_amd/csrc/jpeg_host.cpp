@@ -1,9 +1,9 @@
 // JPEG entropy decoding on the host (the part of `Image.open(path).convert('RGB')`,
-// ref/modules/loader.py:15, that is inherently serial): marker parsing and Huffman decoding of baseline / extended-sequential
-// 8-bit JPEG (SOF0 / SOF1) into quantised DCT coefficient blocks.  Everything after it -- dequantisation, the inverse DCT,
+// ref/modules/loader.py:15, that is inherently serial): marker parsing and Huffman decoding of baseline / extended-sequential /
+// progressive 8-bit JPEG (SOF0 / SOF1 / SOF2) into quantised DCT coefficient blocks.  Everything after it -- dequantisation, the inverse DCT,
 // chroma upsampling and the colour transform -- runs on the GPU (csrc/jpeg.hip) and reproduces libjpeg-turbo's decoder (the one
 // Pillow links) bit for bit.  Written from the JPEG standard (ITU-T T.81): Annex B (markers), C (table construction), F.2.2
-// (sequential Huffman decoding), figure A.6 (zig-zag order).
+// (sequential Huffman decoding), G.1.2 (progressive: spectral selection and successive approximation), figure A.6 (zig-zag order).
 #include <atomic>
 #include <cstdint>
 #include <cstring>
@@ -200,9 +200,20 @@ int parse(const uint8_t* data, size_t n, Parsed& P, int16_t* coefs) {
     } else if (m == 0xDA) {
       if (!P.have_sof) return KLAB_ERR_BADARG;
       if (!coefs) return KLAB_OK;  // header only
-      if (P.progressive || P.precision != 8) return KLAB_ERR_UNSUPPORTED;
+      if (P.precision != 8) return KLAB_ERR_UNSUPPORTED;
       const int ns = s[0];
       if (ns < 1 || ns > P.ncomp || len < 6 + 2 * ns) return KLAB_ERR_BADARG;
+      const int Ss = s[1 + 2 * ns], Se = s[2 + 2 * ns], Ah = s[3 + 2 * ns] >> 4, Al = s[3 + 2 * ns] & 15;
+      // scan kind: 0 sequential; progressive (T.81 G.1.2): 1 DC first, 2 DC refinement, 3 AC first, 4 AC refinement
+      int kind = 0;
+      if (P.progressive) {
+        if (Ss > Se || Se > 63 || Al > 13 || (Ss == 0 && Se != 0) || (Ss > 0 && ns != 1) || (Ah != 0 && Ah != Al + 1)) return KLAB_ERR_BADARG;
+        kind = Ss == 0 ? (Ah == 0 ? 1 : 2) : (Ah == 0 ? 3 : 4);
+      } else if (ns != P.ncomp) {
+        // sequential files: one interleaved scan over whole MCUs (what every baseline encoder in common use writes); a file that
+        // codes its components in separate scans is reported as unsupported rather than taken down a path no test file exercises
+        return KLAB_ERR_UNSUPPORTED;
+      }
       int sc[4];
       for (int i = 0; i < ns; ++i) {
         const int cid = s[1 + 2 * i];
@@ -211,16 +222,23 @@ int parse(const uint8_t* data, size_t n, Parsed& P, int16_t* coefs) {
         if (ci < 0) return KLAB_ERR_BADARG;
         P.comp[ci].td = s[2 + 2 * i] >> 4;
         P.comp[ci].ta = s[2 + 2 * i] & 15;
-        if (P.comp[ci].td > 3 || P.comp[ci].ta > 3 || !P.dc[P.comp[ci].td].defined || !P.ac[P.comp[ci].ta].defined) return KLAB_ERR_BADARG;
+        if (P.comp[ci].td > 3 || P.comp[ci].ta > 3) return KLAB_ERR_BADARG;
+        if ((kind == 0 || kind == 1) && !P.dc[P.comp[ci].td].defined) return KLAB_ERR_BADARG;
+        if ((kind == 0 || kind >= 3) && !P.ac[P.comp[ci].ta].defined) return KLAB_ERR_BADARG;
         sc[i] = ci;
       }
       // ---- entropy-coded segment -------------------------------------------------------------
       Reader r{se, end};
       int pred[4] = {0, 0, 0, 0};
-      // one interleaved scan over whole MCUs (what every baseline encoder in common use writes); a file that codes its
-      // components in separate scans is reported as unsupported rather than taken down a path no test file exercises
-      if (ns != P.ncomp) return KLAB_ERR_UNSUPPORTED;
-      const int mx = P.mcus_x, my = P.mcus_y;
+      int eobrun = 0;
+      // an interleaved scan runs over MCUs, a one-component scan over that component's own block grid (T.81 A.2.2)
+      int mx = P.mcus_x, my = P.mcus_y;
+      if (ns == 1) {
+        const Comp& c = P.comp[sc[0]];
+        mx = ((P.width * c.h + P.hmax - 1) / P.hmax + 7) / 8;
+        my = ((P.height * c.v + P.vmax - 1) / P.vmax + 7) / 8;
+      }
+      const int p1 = 1 << Al, m1 = -(1 << Al);
       int until_restart = P.restart_interval, next_rst = 0;
       for (int y = 0; y < my; ++y)
         for (int x = 0; x < mx; ++x) {
@@ -236,33 +254,102 @@ int parse(const uint8_t* data, size_t n, Parsed& P, int16_t* coefs) {
             next_rst = (next_rst + 1) & 7;
             r.p = q;
             pred[0] = pred[1] = pred[2] = pred[3] = 0;
+            eobrun = 0;
             until_restart = P.restart_interval;
           }
           for (int i = 0; i < ns; ++i) {
             const Comp& c = P.comp[sc[i]];
-            const int nh = c.h, nv = c.v;
+            const int nh = ns == 1 ? 1 : c.h, nv = ns == 1 ? 1 : c.v;
             for (int by = 0; by < nv; ++by)
               for (int bx = 0; bx < nh; ++bx) {
                 const int gx = x * nh + bx, gy = y * nv + by;
                 int16_t* blk = coefs + (c.block0 + (long long)gy * c.bw + gx) * 64;
-                const int sdc = r.decode(P.dc[c.td]);
-                if (sdc < 0 || sdc > 15) return KLAB_ERR_BADARG;
-                pred[sc[i]] += r.receive_extend(sdc);
-                blk[0] = (int16_t)pred[sc[i]];
-                const Huff& ha = P.ac[c.ta];
-                for (int k = 1; k < 64;) {
-                  const int rs = r.decode(ha);
-                  if (rs < 0) return KLAB_ERR_BADARG;
-                  const int run = rs >> 4, sz = rs & 15;
-                  if (sz == 0) {
-                    if (run != 15) break;
-                    k += 16;
-                    continue;
+                if (kind == 0 || kind == 1) {  // DC coefficient: Huffman-coded difference to the previous block of the component
+                  const int sdc = r.decode(P.dc[c.td]);
+                  if (sdc < 0 || sdc > 15) return KLAB_ERR_BADARG;
+                  pred[sc[i]] += r.receive_extend(sdc);
+                  blk[0] = (int16_t)(kind == 1 ? pred[sc[i]] * (1 << Al) : pred[sc[i]]);
+                }
+                if (kind == 0) {
+                  const Huff& ha = P.ac[c.ta];
+                  for (int k = 1; k < 64;) {
+                    const int rs = r.decode(ha);
+                    if (rs < 0) return KLAB_ERR_BADARG;
+                    const int run = rs >> 4, sz = rs & 15;
+                    if (sz == 0) {
+                      if (run != 15) break;
+                      k += 16;
+                      continue;
+                    }
+                    k += run;
+                    if (k > 63) return KLAB_ERR_BADARG;
+                    blk[kZigzag[k]] = (int16_t)r.receive_extend(sz);
+                    ++k;
                   }
-                  k += run;
-                  if (k > 63) return KLAB_ERR_BADARG;
-                  blk[kZigzag[k]] = (int16_t)r.receive_extend(sz);
-                  ++k;
+                } else if (kind == 2) {  // DC refinement: one more bit of every DC coefficient
+                  if (r.nbits < 1) r.fill();
+                  if (r.peek(1)) blk[0] = (int16_t)(blk[0] | p1);
+                  r.drop(1);
+                } else if (kind == 3) {  // AC first pass of the band Ss..Se, with end-of-band runs over blocks (G.1.2.2)
+                  if (eobrun > 0) { --eobrun; continue; }
+                  const Huff& ha = P.ac[c.ta];
+                  for (int k = Ss; k <= Se; ++k) {
+                    const int rs = r.decode(ha);
+                    if (rs < 0) return KLAB_ERR_BADARG;
+                    const int run = rs >> 4, sz = rs & 15;
+                    if (sz) {
+                      k += run;
+                      if (k > 63) return KLAB_ERR_BADARG;
+                      blk[kZigzag[k]] = (int16_t)(r.receive_extend(sz) * (1 << Al));
+                    } else if (run == 15) {
+                      k += 15;
+                    } else {
+                      eobrun = 1 << run;
+                      if (run) { if (r.nbits < run) r.fill(); eobrun += (int)r.peek(run); r.drop(run); }
+                      --eobrun;
+                      break;
+                    }
+                  }
+                } else if (kind == 4) {  // AC refinement (G.1.2.3): correction bits for the non-zero history, newly non-zero coefficients of +-2^Al
+                  const Huff& ha = P.ac[c.ta];
+                  int k = Ss;
+                  auto refine = [&](int16_t& cf) {
+                    if (r.nbits < 1) r.fill();
+                    const int bit = (int)r.peek(1);
+                    r.drop(1);
+                    if (bit && (cf & p1) == 0) cf = (int16_t)(cf >= 0 ? cf + p1 : cf + m1);
+                  };
+                  if (eobrun == 0) {
+                    for (; k <= Se; ++k) {
+                      const int rs = r.decode(ha);
+                      if (rs < 0) return KLAB_ERR_BADARG;
+                      int run = rs >> 4, sz = rs & 15, val = 0;
+                      if (sz) {
+                        if (sz != 1) return KLAB_ERR_BADARG;
+                        if (r.nbits < 1) r.fill();
+                        val = r.peek(1) ? p1 : m1;
+                        r.drop(1);
+                      } else if (run != 15) {
+                        eobrun = 1 << run;
+                        if (run) { if (r.nbits < run) r.fill(); eobrun += (int)r.peek(run); r.drop(run); }
+                        break;  // the rest of the band is handled by the end-of-band branch below
+                      }
+                      // skip `run` zero-history coefficients, refining the non-zero ones passed on the way
+                      for (; k <= Se; ++k) {
+                        int16_t& cf = blk[kZigzag[k]];
+                        if (cf != 0) refine(cf);
+                        else if (--run < 0) break;
+                      }
+                      if (val && k <= Se) blk[kZigzag[k]] = (int16_t)val;
+                    }
+                  }
+                  if (eobrun > 0) {
+                    for (; k <= Se; ++k) {
+                      int16_t& cf = blk[kZigzag[k]];
+                      if (cf != 0) refine(cf);
+                    }
+                    --eobrun;
+                  }
                 }
               }
           }
@@ -305,7 +392,7 @@ int fill_info(const Parsed& P, klab_jpeg_info* o) {
 }
 
 bool supported(const Parsed& P) {
-  if (P.progressive || P.precision != 8 || (P.ncomp != 1 && P.ncomp != 3)) return false;
+  if (P.precision != 8 || (P.ncomp != 1 && P.ncomp != 3)) return false;
   if (P.ncomp == 3) {
     // luma at full resolution, both chroma planes with the same factors, 1x1 / 2x1 / 2x2 sub-sampling
     if (P.comp[0].h != P.hmax || P.comp[0].v != P.vmax) return false;

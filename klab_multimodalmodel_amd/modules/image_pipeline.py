@@ -13,8 +13,8 @@ reference effectively does) and normalisation (`csrc/image_pre.hip`).  Entry poi
     GpuImageProcessor().from_decoded(arrays)    list of decoded HWC uint8 RGB images of ANY size (numpy / PIL.Image / tensor):
                                                 replaces loader.py:15-16 as well (use `DatasetLoader(decode_only=True)`)
     GpuImageProcessor().from_jpeg(files)        list of JPEG files (paths or bytes): replaces `Image.open(path).convert('RGB')` too.
-                                                Baseline / extended-sequential files; a progressive, CMYK or multi-scan file raises
-                                                NotImplementedError (decode that one with PIL and pass it to from_decoded)
+                                                Baseline and progressive Huffman files; a CMYK, 12-bit or arithmetic-coded file
+                                                raises NotImplementedError (decode that one with PIL and pass it to from_decoded)
 
 Both return {"pixel_values": cuda float32 [B, 3, 224, 224]} -- what `MyModel.forward` takes.  No CPU fallback: without the HIP
 library the call raises.

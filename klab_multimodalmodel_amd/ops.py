@@ -329,7 +329,7 @@ def jpeg_read_info(data: bytes):
 def jpeg_entropy_decode_batch(datas, n_threads=8):
     """Huffman-decode a list of JPEG byte strings on the host (threaded).  Returns (coefs int16 numpy [total_blocks, 64] in pinned
     memory when CUDA is available, qt uint16 numpy [n, 3, 64], items = (_lib.JpegItem * n) with coef_block0 filled, rgb_off = byte
-    offsets of 16-byte aligned HWC RGB images, total RGB bytes).  Unsupported files (progressive, CMYK, ...) raise
+    offsets of 16-byte aligned HWC RGB images, total RGB bytes).  Unsupported files (CMYK, 12-bit, arithmetic-coded, ...) raise
     NotImplementedError naming the index."""
     import numpy as np
     import torch

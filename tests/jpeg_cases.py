@@ -1,5 +1,6 @@
 """JPEG files for the decoder tests, produced with Pillow's encoder: every sampling mode, grey, odd sizes (partial MCUs), widths
-of 1-5 pixels (the non-"fancy" upsampling branch), restart intervals, optimised Huffman tables, extreme quality settings."""
+of 1-5 pixels (the non-"fancy" upsampling branch), restart intervals, optimised Huffman tables, extreme quality settings,
+progressive files."""
 import io
 
 import numpy as np
@@ -40,6 +41,18 @@ def jpeg_cases():
         try:
             add(f"420_restart{ri}", _img(rng, 75, 99, "smooth"), quality=80, subsampling=2, restart_marker_blocks=ri)
             add(f"444_restart_rows{ri}", _img(rng, 50, 70, "noise"), quality=60, subsampling=0, restart_marker_rows=ri)
+        except TypeError:
+            pass
+    # progressive files (spectral selection + successive approximation, one-component AC scans over the component's own block grid)
+    for sub, sname in ((0, "444"), (1, "422"), (2, "420")):
+        for (h, w) in ((64, 64), (37, 53), (120, 9), (8, 8), (1, 1), (33, 3), (200, 301)):
+            for kind in ("noise", "smooth", "edges"):
+                add(f"prog_{sname}_{h}x{w}_{kind}", _img(rng, h, w, kind), quality=int(rng.integers(20, 96)), subsampling=sub, progressive=True)
+    add("prog_420_optimize_q100", _img(rng, 90, 131, "noise"), quality=100, subsampling=2, progressive=True, optimize=True)
+    add("prog_grey", _img(rng, 77, 45, "smooth"), mode="L", quality=60, progressive=True)
+    for ri in (1, 3):
+        try:
+            add(f"prog_420_restart{ri}", _img(rng, 75, 99, "smooth"), quality=80, subsampling=2, progressive=True, restart_marker_blocks=ri)
         except TypeError:
             pass
     add("grey_50x70", _img(rng, 50, 70, "smooth"), mode="L", quality=75)

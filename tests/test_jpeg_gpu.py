@@ -70,13 +70,16 @@ def test_from_jpeg_equals_from_decoded():
     buf = io.BytesIO()
     Image.fromarray(rng.integers(0, 255, (300, 200), dtype=np.uint8), "L").save(buf, "JPEG", quality=70)
     datas.append(buf.getvalue())
+    buf = io.BytesIO()
+    Image.fromarray(a).save(buf, "JPEG", quality=85, progressive=True)
+    datas.append(buf.getvalue())
     proc = GpuImageProcessor.from_pretrained("microsoft/swinv2-base-patch4-window8-256")
     a = proc.from_jpeg(datas)["pixel_values"]
     b = proc.from_decoded([Image.open(io.BytesIO(d)).convert("RGB") for d in datas])["pixel_values"]
     torch.cuda.synchronize()
     assert a.shape == b.shape == (len(datas), 3, 256, 256)
     assert torch.equal(a, b)
-    prog = io.BytesIO()
-    Image.fromarray(rng.integers(0, 255, (32, 32, 3), dtype=np.uint8)).save(prog, "JPEG", progressive=True)
+    cmyk = io.BytesIO()
+    Image.fromarray(rng.integers(0, 255, (32, 32, 3), dtype=np.uint8)).convert("CMYK").save(cmyk, "JPEG")
     with pytest.raises(NotImplementedError):
-        proc.from_jpeg([prog.getvalue()])
+        proc.from_jpeg([cmyk.getvalue()])
