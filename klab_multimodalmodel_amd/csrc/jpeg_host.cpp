@@ -73,6 +73,17 @@ struct Reader {
   bool hit_marker = false;
   void reset() { buf = 0; nbits = 0; hit_marker = false; }
   inline void fill() {
+    // fast path: four data bytes at once when none of them is 0xFF (no stuffing, no marker); afterwards nbits >= 32
+    if (!hit_marker && nbits <= 32 && p + 4 <= end) {
+      const uint32_t w = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+      const uint32_t inv = ~w;
+      if (((inv - 0x01010101u) & w & 0x80808080u) == 0) {  // no byte of ~w is zero
+        buf |= (uint64_t)w << (32 - nbits);
+        nbits += 32;
+        p += 4;
+        return;
+      }
+    }
     while (nbits <= 56) {
       uint32_t b = 0;
       if (!hit_marker && p < end) {
@@ -94,10 +105,10 @@ struct Reader {
     if (nbits < s) fill();
     const int v = (int)peek(s);
     drop(s);
-    return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
+    return v - ((((v >> (s - 1)) & 1) - 1) & ((1 << s) - 1));  // v < 2^(s-1): v - (2^s - 1)
   }
   inline int decode(const Huff& h) {
-    if (nbits < 16) fill();
+    if (nbits < 32) fill();  // a code (<= 16 bits) and the value bits behind it (<= 15) without another refill
     const uint32_t look = peek(9);
     int l = h.look_len[look];
     if (l) { drop(l); return h.look_sym[look]; }
