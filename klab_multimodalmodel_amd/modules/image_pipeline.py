@@ -149,7 +149,7 @@ class GpuImageProcessor:
                              std=self.std)
         return BatchFeature(pixel_values=pv)
 
-    def from_jpeg(self, files, n_threads=8):
+    def from_jpeg(self, files, n_threads=None):
         """list of JPEG files (paths, bytes or binary file objects) -> pixel_values; `Image.open(f).convert('RGB')` + from_decoded"""
         datas = []
         for f in files:
@@ -160,8 +160,10 @@ class GpuImageProcessor:
             else:
                 with open(f, "rb") as fh:
                     datas.append(fh.read())
-        coefs_t, qt, items, rgb_bytes = ops.jpeg_entropy_decode_batch(datas, n_threads)
-        rgb, desc = ops.jpeg_decode_device(coefs_t, qt, items, rgb_bytes, self.device)
+        if n_threads is None:
+            import os
+            n_threads = min(16, os.cpu_count() or 1)
+        rgb, desc, items = ops.jpeg_decode_pipelined(datas, self.device, n_threads)
         n = len(datas)
         pv = self._out(n)
         ops.image_preprocess(rgb, desc, n, max(it.info.height for it in items), max(it.info.width for it in items), pv, mid=self.loader_size,

@@ -321,8 +321,8 @@ def jpeg_read_info(data: bytes):
     """header of one JPEG file (host only): a _lib.JpegInfo"""
     lib = L.load()
     info = L.JpegInfo()
-    buf = (C.c_ubyte * len(data)).from_buffer_copy(data)
-    L.check(lib.klab_jpeg_read_info(C.cast(buf, C.c_void_p), len(data), C.byref(info)), "klab_jpeg_read_info")
+    data = data if isinstance(data, bytes) else bytes(data)
+    L.check(lib.klab_jpeg_read_info(C.cast(C.c_char_p(data), C.c_void_p), len(data), C.byref(info)), "klab_jpeg_read_info")
     return info
 
 
@@ -336,7 +336,8 @@ def jpeg_entropy_decode_batch(datas, n_threads=8):
     lib = L.load()
     n = len(datas)
     items = (L.JpegItem * n)()
-    bufs = [(C.c_ubyte * len(d)).from_buffer_copy(d) for d in datas]
+    datas = [d if isinstance(d, bytes) else bytes(d) for d in datas]
+    bufs = [C.c_char_p(d) for d in datas]  # pointers into the bytes objects (read-only use, `datas` outlives the calls)
     blocks, rgb = 0, 0
     for i, d in enumerate(datas):
         L.check(lib.klab_jpeg_read_info(C.cast(bufs[i], C.c_void_p), len(d), C.byref(items[i].info)), f"klab_jpeg_read_info[{i}]")
@@ -390,12 +391,76 @@ def jpeg_decode_device(coefs_t, qt, items, rgb_bytes, device="cuda"):
     return rgb, torch.from_numpy(desc).to(dev)
 
 
-def jpeg_decode(datas, device="cuda", n_threads=8):
+def jpeg_decode(datas, device="cuda", n_threads=8, pipelined=False):
     """list of JPEG byte strings -> list of HWC uint8 RGB device tensors (views into one buffer): `Image.open(f).convert('RGB')`"""
-    coefs_t, qt, items, rgb_bytes = jpeg_entropy_decode_batch(datas, n_threads)
-    rgb, _desc = jpeg_decode_device(coefs_t, qt, items, rgb_bytes, device)
+    if pipelined:
+        rgb, _desc, items = jpeg_decode_pipelined(datas, device, n_threads)
+    else:
+        coefs_t, qt, items, rgb_bytes = jpeg_entropy_decode_batch(datas, n_threads)
+        rgb, _desc = jpeg_decode_device(coefs_t, qt, items, rgb_bytes, device)
     out = []
     for it in items:
         h, w = it.info.height, it.info.width
         out.append(rgb[it.rgb_off:it.rgb_off + h * w * 3].view(h, w, 3))
     return out
+
+
+def jpeg_decode_pipelined(datas, device="cuda", n_threads=8, n_chunks=4):
+    """file bytes -> (rgb device buffer, desc device tensor [n, 2] in the klab_image_desc layout, items).  The batch is cut into
+    chunks: while the host threads Huffman-decode chunk i+1, chunk i's coefficients cross PCIe and are reconstructed on the GPU
+    (the copies and kernels are asynchronous on the current stream; the host never waits for the device)."""
+    import numpy as np
+    import torch
+    lib = L.load()
+    n = len(datas)
+    dev = torch.device(device)
+    datas = [d if isinstance(d, bytes) else bytes(d) for d in datas]
+    items = (L.JpegItem * n)()
+    blocks, rgb_bytes = 0, 0
+    for i, d in enumerate(datas):
+        L.check(lib.klab_jpeg_read_info(C.cast(C.c_char_p(d), C.c_void_p), len(d), C.byref(items[i].info)), f"klab_jpeg_read_info[{i}]")
+        f = items[i].info
+        if not f.supported:
+            raise NotImplementedError(f"klab: JPEG {i} is outside the device decoder (components={f.ncomp}, precision={f.precision}, "
+                                      f"sampling={list(f.hs)}x{list(f.vs)})")
+        items[i].coef_block0, items[i].rgb_off = blocks, rgb_bytes
+        blocks += f.coef_blocks
+        rgb_bytes += (f.width * f.height * 3 + 15) // 16 * 16
+    coefs_t = torch.empty((max(blocks, 1), 64), dtype=torch.int16, pin_memory=True)
+    qt_t = torch.zeros((n, 192), dtype=torch.int16, pin_memory=True)
+    coefs, qt = coefs_t.numpy(), qt_t.numpy()
+    coefs_dev = torch.empty((max(blocks, 1), 64), dtype=torch.int16, device=dev)
+    qt_dev = torch.empty((n, 192), dtype=torch.int16, device=dev)
+    items_dev = torch.from_numpy(np.frombuffer(bytes(items), dtype=np.uint8).copy()).to(dev)
+    rgb = torch.empty(max(rgb_bytes, 16), dtype=torch.uint8, device=dev)
+    isz = C.sizeof(L.JpegItem)
+    per = max(1, -(-n // max(1, n_chunks)))
+    keep = []
+    for lo in range(0, n, per):
+        hi = min(n, lo + per)
+        m = hi - lo
+        ptrs = (C.c_void_p * m)(*[C.cast(C.c_char_p(datas[i]), C.c_void_p) for i in range(lo, hi)])
+        sizes = (C.c_size_t * m)(*[len(datas[i]) for i in range(lo, hi)])
+        cps = (C.c_void_p * m)(*[coefs.ctypes.data + items[i].coef_block0 * 128 for i in range(lo, hi)])
+        rcs = (C.c_int * m)()
+        rc = lib.klab_jpeg_entropy_decode_batch(C.cast(ptrs, C.c_void_p), C.cast(sizes, C.c_void_p), m, C.cast(cps, C.c_void_p),
+                                                qt.ctypes.data + lo * 384, None, C.cast(rcs, C.c_void_p), int(n_threads))
+        if rc:
+            bad = [lo + i for i in range(m) if rcs[i]]
+            L.check(rcs[bad[0] - lo] if bad else rc, f"klab_jpeg_entropy_decode_batch (images {bad})")
+        b0 = items[lo].coef_block0
+        b1 = items[hi - 1].coef_block0 + items[hi - 1].info.coef_blocks
+        coefs_dev[b0:b1].copy_(coefs_t[b0:b1], non_blocking=True)
+        qt_dev[lo:hi].copy_(qt_t[lo:hi], non_blocking=True)
+        host_items = C.cast(C.addressof(items) + lo * isz, C.c_void_p)
+        nbytes = lib.klab_jpeg_decode_ws_bytes(host_items, m)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        keep.append(ws)
+        # qt index of image i in the kernel is (i - lo) * 3 + c: pass the chunk's slice of the table
+        L.check(lib.klab_jpeg_decode_device(coefs_dev.data_ptr(), qt_dev.data_ptr() + lo * 384, host_items, items_dev.data_ptr() + lo * isz, m,
+                                            rgb.data_ptr(), ws.data_ptr(), nbytes, L.stream_ptr()), "klab_jpeg_decode_device")
+    desc = np.zeros((n, 2), np.int64)
+    for i in range(n):
+        desc[i, 0] = items[i].rgb_off
+        desc[i, 1] = items[i].info.height | (items[i].info.width << 32)
+    return rgb, torch.from_numpy(desc).to(dev), items

@@ -22,14 +22,15 @@ def _pil(data):
 def test_device_decode_is_pillow_exact():
     from klab_multimodalmodel_amd import ops
     cases = jpeg_cases()
-    outs = ops.jpeg_decode([d for _n, d in cases])  # ONE batch: every sampling mode / size side by side in the same launches
-    torch.cuda.synchronize()
-    for (name, data), got in zip(cases, outs):
-        want = _pil(data)
-        g = got.cpu().numpy()
-        assert g.shape == want.shape, (name, g.shape, want.shape)
-        bad = int((g != want).sum())
-        assert bad == 0, (name, bad, int(np.abs(g.astype(int) - want.astype(int)).max()))
+    for pipelined in (False, True):  # one batch in one go / cut into chunks whose host and device halves overlap
+        outs = ops.jpeg_decode([d for _n, d in cases], pipelined=pipelined)  # every sampling mode / size side by side in the same launches
+        torch.cuda.synchronize()
+        for (name, data), got in zip(cases, outs):
+            want = _pil(data)
+            g = got.cpu().numpy()
+            assert g.shape == want.shape, (name, g.shape, want.shape)
+            bad = int((g != want).sum())
+            assert bad == 0, (pipelined, name, bad, int(np.abs(g.astype(int) - want.astype(int)).max()))
 
 
 def test_device_decode_matches_oracle_on_synthetic_coefficients():
