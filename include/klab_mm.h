@@ -114,6 +114,11 @@ int klab_layernorm_fwd(const void* y, int y_dtype, const float* gamma, const flo
 int klab_layernorm_bwd(const float* dout, const void* y, int y_dtype, const float* gamma, const float* mean,
                        const float* rstd, void* dy, float* dgamma, float* dbeta, int rows, int C, int grp,
                        int grp_stride, int off, float drop_p, const uint32_t* seed_dev, uint32_t tag, void* stream);
+/* the same, and dprev_bias[c] += sum_rows dy[:, c] -- the bias gradient of the Linear whose output the norm consumed (its input
+ * gradient is dy) -- in the same pass (C <= 1024: one fused kernel for dy, dgamma, dbeta and dprev_bias)                      */
+int klab_layernorm_bwd_bias(const float* dout, const void* y, int y_dtype, const float* gamma, const float* mean,
+                            const float* rstd, void* dy, float* dgamma, float* dbeta, float* dprev_bias, int rows, int C, int grp,
+                            int grp_stride, int off, float drop_p, const uint32_t* seed_dev, uint32_t tag, void* stream);
 
 /* ---- T5 attention core (HF/t5:144-173 as called from :281-369) ------------------------------
  * S = Q K^T (unscaled, HF/t5:196-197) + bias[h,Lq,Lk] (+ causal); P = softmax(S); ctx = drop(P) V.

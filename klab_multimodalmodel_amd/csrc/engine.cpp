@@ -1755,11 +1755,10 @@ int swin_backward(const Ctx& c, const float* dh0, float p_in) {
       void* dqkv = side_on ? e->sdqkvP[par] : e->sdqkv;
       const Ctx& cw = side_on ? cs : c;                // where the weight gradients go
       // h2 = h1 + LN2(fo):  d fo = LN2'(dh);  dh flows through the shortcut unchanged
-      RC(klab_layernorm_bwd(dh, q.fo, c.dt, W[ix.ln2w], q.mean2, q.rstd2, dyA, G(ix.ln2w), G(ix.ln2b), M, C, 0, 0, 0, 0.f, nullptr, 0, c.ws()));
-      if (!side_on) {
-        RC(klab_colsum(dyA, C, c.dt, M, C, G(ix.f2b), c.ws()));
-        RC(linear_wgrad(c, dyA, C, q.a, F, M, C, F, G(ix.f2w)));
-      }
+      // (the column sums of d fo are fc2's bias gradient: folded into the same pass)
+      RC(klab_layernorm_bwd_bias(dh, q.fo, c.dt, W[ix.ln2w], q.mean2, q.rstd2, dyA, G(ix.ln2w), G(ix.ln2b), G(ix.f2b), M, C, 0, 0, 0, 0.f, nullptr,
+                                 0, c.ws()));
+      if (!side_on) RC(linear_wgrad(c, dyA, C, q.a, F, M, C, F, G(ix.f2w)));
       {  // d z = (d fo @ W2) * gelu'(z)
         klab_gemm_args g = G0(c, M, F, C, dyA, C, 1, woff(c, P[ix.f2w].warena_off), F, 0, da, F, c.dt);
         g.aux = q.z; g.ldaux = F; g.aux_mode = KLAB_AUX_DGELU;
@@ -1775,11 +1774,9 @@ int swin_backward(const Ctx& c, const float* dh0, float p_in) {
         RC(klab_gemm(&g, c.ws()));
       }
       // h1 = x + LN1(po)
-      RC(klab_layernorm_bwd(dh, q.po, c.dt, W[ix.ln1w], q.mean1, q.rstd1, dyB, G(ix.ln1w), G(ix.ln1b), M, C, 0, 0, 0, 0.f, nullptr, 0, c.ws()));
-      if (!side_on) {
-        RC(klab_colsum(dyB, C, c.dt, M, C, G(ix.pb), c.ws()));
-        RC(linear_wgrad(c, dyB, C, q.ctx, C, M, C, C, G(ix.pw)));
-      }
+      RC(klab_layernorm_bwd_bias(dh, q.po, c.dt, W[ix.ln1w], q.mean1, q.rstd1, dyB, G(ix.ln1w), G(ix.ln1b), G(ix.pb), M, C, 0, 0, 0, 0.f, nullptr,
+                                 0, c.ws()));
+      if (!side_on) RC(linear_wgrad(c, dyB, C, q.ctx, C, M, C, C, G(ix.pw)));
       RC(linear_dgrad(c, dyB, C, M, C, P[ix.pw].warena_off, C, e->sdctx, c.dt));
       klab_swin_attn_args a;
       memset(&a, 0, sizeof(a));
@@ -1803,9 +1800,7 @@ int swin_backward(const Ctx& c, const float* dh0, float p_in) {
       }
       if (side_on) {  // everything the block's weight gradients read exists now: release them to the side stream
         RC(side_after_main(c));
-        RC(klab_colsum(dyA, C, c.dt, M, C, G(ix.f2b), cw.ws()));
         RC(klab_colsum(da, F, c.dt, M, F, G(ix.f1b), cw.ws()));
-        RC(klab_colsum(dyB, C, c.dt, M, C, G(ix.pb), cw.ws()));
       }
       if (ix.qb >= 0) {
         RC(klab_colsum(dqkv, 3 * C, c.dt, M, C, G(ix.qb), cw.ws()));
@@ -1841,9 +1836,8 @@ int swin_backward(const Ctx& c, const float* dh0, float p_in) {
   // patch embedding: LN -> conv-as-GEMM (weights + bias only; pixels need no gradient)
   const long M0 = (long)B * R0 * R0;
   const int K0 = s.in_ch * s.patch * s.patch;
-  RC(klab_layernorm_bwd(dh, e->pe_out, c.dt, W[e->si.penw], e->pe_mean, e->pe_rstd, e->sdy, G(e->si.penw), G(e->si.penb), (int)M0, C0, 0, 0, 0,
-                        0.f, nullptr, 0, c.ws()));
-  RC(klab_colsum(e->sdy, C0, c.dt, (int)M0, C0, G(e->si.peb), c.ws()));
+  RC(klab_layernorm_bwd_bias(dh, e->pe_out, c.dt, W[e->si.penw], e->pe_mean, e->pe_rstd, e->sdy, G(e->si.penw), G(e->si.penb), G(e->si.peb), (int)M0,
+                             C0, 0, 0, 0, 0.f, nullptr, 0, c.ws()));
   RC(linear_wgrad(c, e->sdy, C0, e->cols, e->pe_kp, (int)M0, C0, K0, G(e->si.pew)));
   e->bucket_ev_live[2] = e->bucket_events_on && !e->use_graph;
   return 0;

@@ -360,6 +360,91 @@ __global__ __launch_bounds__(256) void layernorm_dgb_kernel(const float* __restr
   }
 }
 
+// Fused LayerNorm backward for C <= 256*SLOTS (the trainable Swin tower, 52 calls per configs[2] step): one pass over
+// (dout, y) gives the row result dy = LN'(dout) AND the three column sums that used to take two more kernels and two more reads
+// of the activations: dgamma = sum dout*xhat, dbeta = sum dout, and dprev = sum dy -- the bias gradient of the Linear whose output
+// this norm consumed (fc2 / the attention output projection).  One wave per row in flight, every lane keeps the partial sums of
+// its own columns over the workgroup's rows, 16 waves fold through LDS and a workgroup issues one f32 atomic per column and sum.
+template <typename TI, int SLOTS>
+__global__ __launch_bounds__(1024) void layernorm_bwd_fused_kernel(const float* __restrict__ dout, const TI* __restrict__ y,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                  const float* __restrict__ rstd, TI* __restrict__ dy,
+                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                  float* __restrict__ dprev, int rows, int C, int grp, int grp_stride,
+                                                                  int off, float p, const uint32_t* seed, uint32_t tag) {
+  constexpr int WPB = 16;
+  __shared__ float red[WPB][256 * SLOTS];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const DropCtx dc = make_drop(seed, tag, p);
+  f32x4 g[SLOTS], ag[SLOTS], ab[SLOTS], ap[SLOTS];
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    const int c = lane * 4 + s * 256;
+    g[s] = c < C ? *reinterpret_cast<const f32x4*>(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    ag[s] = ab[s] = ap[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (long row = (long)blockIdx.x * WPB + wv; row < rows; row += (long)gridDim.x * WPB) {
+    const TI* yr = y + row * C;
+    const long orow = remap_row(row, grp, grp_stride, off);
+    const float* dor = dout + orow * C;
+    const float mu = mean[row], r = rstd[row];
+    f32x4 xh[SLOTS], e[SLOTS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {  // all loads of the row go out before the first use
+      const int c = lane * 4 + s * 256;
+      xh[s] = e[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < C) { xh[s] = load4<TI>(yr + c); e[s] = *reinterpret_cast<const f32x4*>(dor + c); }
+    }
+    float s1 = 0.f, s2 = 0.f;  // sum(g*do), sum(g*do*xhat)
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      const int c = lane * 4 + s * 256;
+      if (c < C) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          e[s][i] *= drop_mult(dc, (uint64_t)orow * C + c + i);
+          xh[s][i] = (xh[s][i] - mu) * r;
+          s1 += g[s][i] * e[s][i];
+          s2 += g[s][i] * e[s][i] * xh[s][i];
+          ag[s][i] += e[s][i] * xh[s][i];
+          ab[s][i] += e[s][i];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)C;
+    s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      const int c = lane * 4 + s * 256;
+      if (c < C) {
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          o[i] = r * (g[s][i] * e[s][i] - s1 - xh[s][i] * s2);
+          ap[s][i] += o[i];
+        }
+        store4<TI>(dy + row * C + c, o[0], o[1], o[2], o[3]);
+      }
+    }
+  }
+  auto fold = [&](const f32x4 (&a)[SLOTS], float* dst) {
+    if (!dst) return;  // (uniform)
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) *reinterpret_cast<f32x4*>(&red[wv][lane * 4 + s * 256]) = a[s];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 1024) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < WPB; ++w) t += red[w][c];
+      atomicAdd(dst + c, t);
+    }
+  };
+  fold(ag, dgamma);
+  fold(ab, dbeta);
+  fold(ap, dprev);
+}
+
 static inline int norm_grid(int rows) {
   int g = (rows + 3) / 4;
   return g < 1 ? 1 : (g > 2048 ? 2048 : g);
@@ -496,13 +581,24 @@ extern "C" int klab_layernorm_fwd(const void* y, int y_dtype, const float* gamma
   return KLAB_OK;
 }
 
-extern "C" int klab_layernorm_bwd(const float* dout, const void* y, int y_dtype, const float* gamma, const float* mean,
-                                  const float* rstd, void* dy, float* dgamma, float* dbeta, int rows, int C, int grp,
-                                  int grp_stride, int off, float drop_p, const uint32_t* seed_dev, uint32_t tag,
-                                  void* stream) {
+static int layernorm_bwd_impl(const float* dout, const void* y, int y_dtype, const float* gamma, const float* mean, const float* rstd,
+                              void* dy, float* dgamma, float* dbeta, float* dprev_bias, int rows, int C, int grp, int grp_stride, int off,
+                              float drop_p, const uint32_t* seed_dev, uint32_t tag, hipStream_t s) {
   if (!dout || !y || !gamma || !mean || !rstd || rows < 0 || C <= 0 || (C & 3)) return KLAB_ERR_BADARG;
+  if (dprev_bias && !dy) return KLAB_ERR_BADARG;
   if (rows == 0) return KLAB_OK;
-  hipStream_t s = (hipStream_t)stream;
+  static const bool fused_on = [] { const char* e = getenv("KLAB_LN_BWD_FUSED"); return !e || atoi(e) != 0; }();
+  if (dy && (dgamma || dbeta || dprev_bias) && C <= 1024 && fused_on) {
+    const int gf = rms_part_rows(rows);
+#define LNB(TI, SL)                                                                                                                   \
+    hipLaunchKernelGGL((layernorm_bwd_fused_kernel<TI, SL>), dim3(gf), dim3(1024), 0, s, dout, (const TI*)y, gamma, mean, rstd, (TI*)dy, \
+                       dgamma, dbeta, dprev_bias, rows, C, grp, grp_stride, off, drop_p, seed_dev, tag)
+    if (y_dtype == KLAB_BF16) { if (C <= 256) LNB(bf16_t, 1); else if (C <= 512) LNB(bf16_t, 2); else LNB(bf16_t, 4); }
+    else { if (C <= 256) LNB(float, 1); else if (C <= 512) LNB(float, 2); else LNB(float, 4); }
+#undef LNB
+    KLAB_LAUNCH_CHECK();
+    return KLAB_OK;
+  }
   const int g = norm_grid(rows);
   int gy = (rows + 63) / 64;
   gy = gy < 1 ? 1 : (gy > 128 ? 128 : gy);
@@ -519,5 +615,24 @@ extern "C" int klab_layernorm_bwd(const float* dout, const void* y, int y_dtype,
                                             dbeta, rows, C, grp, grp_stride, off, drop_p, seed_dev, tag);
   }
   KLAB_LAUNCH_CHECK();
+  if (dprev_bias) return klab_colsum(dy, C, y_dtype, rows, C, dprev_bias, (void*)s);  // wide rows: the separate column sum
   return KLAB_OK;
+}
+
+extern "C" int klab_layernorm_bwd(const float* dout, const void* y, int y_dtype, const float* gamma, const float* mean,
+                                  const float* rstd, void* dy, float* dgamma, float* dbeta, int rows, int C, int grp,
+                                  int grp_stride, int off, float drop_p, const uint32_t* seed_dev, uint32_t tag,
+                                  void* stream) {
+  return layernorm_bwd_impl(dout, y, y_dtype, gamma, mean, rstd, dy, dgamma, dbeta, nullptr, rows, C, grp, grp_stride, off, drop_p, seed_dev,
+                            tag, (hipStream_t)stream);
+}
+
+// as klab_layernorm_bwd, and dprev_bias[c] += sum over rows of dy[:, c]: the bias gradient of the Linear layer whose output the
+// norm consumed (its input gradient IS dy), folded into the same pass
+extern "C" int klab_layernorm_bwd_bias(const float* dout, const void* y, int y_dtype, const float* gamma, const float* mean,
+                                       const float* rstd, void* dy, float* dgamma, float* dbeta, float* dprev_bias, int rows, int C,
+                                       int grp, int grp_stride, int off, float drop_p, const uint32_t* seed_dev, uint32_t tag,
+                                       void* stream) {
+  return layernorm_bwd_impl(dout, y, y_dtype, gamma, mean, rstd, dy, dgamma, dbeta, dprev_bias, rows, C, grp, grp_stride, off, drop_p,
+                            seed_dev, tag, (hipStream_t)stream);
 }

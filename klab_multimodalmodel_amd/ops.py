@@ -126,9 +126,14 @@ def swin_mlp_fused(x, shortcut, w1, b1, w2, b2, gamma, beta, out, outt=None, eps
 
 
 def layernorm_bwd(dout, y, gamma, mean, rstd, dy=None, dgamma=None, dbeta=None, grp=0, grp_stride=0, off=0, drop_p=0.0,
-                  seed=None, tag=0):
+                  seed=None, tag=0, dprev_bias=None):
     lib = L.load()
     rows, Cc = y.shape
+    if dprev_bias is not None:
+        L.check(lib.klab_layernorm_bwd_bias(dout.data_ptr(), y.data_ptr(), L.dtype_code(y.dtype), gamma.data_ptr(), mean.data_ptr(),
+                                            rstd.data_ptr(), L.ptr(dy), L.ptr(dgamma), L.ptr(dbeta), dprev_bias.data_ptr(), rows, Cc, grp,
+                                            grp_stride, off, drop_p, _seed_ptr(seed), tag, L.stream_ptr()), "klab_layernorm_bwd_bias")
+        return
     L.check(lib.klab_layernorm_bwd(dout.data_ptr(), y.data_ptr(), L.dtype_code(y.dtype), gamma.data_ptr(), mean.data_ptr(),
                                    rstd.data_ptr(), L.ptr(dy), L.ptr(dgamma), L.ptr(dbeta), rows, Cc, grp, grp_stride, off,
                                    drop_p, _seed_ptr(seed), tag, L.stream_ptr()), "klab_layernorm_bwd")

@@ -196,7 +196,7 @@ def test_rmsnorm_row_remap(ops):
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("rows,C", [(48, 16), (200, 64), (64, 512)])
+@pytest.mark.parametrize("rows,C", [(48, 16), (200, 64), (64, 512), (1000, 96), (333, 384), (70, 768), (257, 1024), (40, 1536)])
 def test_layernorm_fwd_bwd(ops, dt, rows, C):
     y, g, b = rnd(rows, C, seed=1).to(dt), 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
     sc, dout = rnd(rows, C, seed=4), rnd(rows, C, seed=5)
@@ -216,6 +216,15 @@ def test_layernorm_fwd_bwd(ops, dt, rows, C):
     assert rel_l2(dy.float().cpu(), yr.grad) < (1e-5 if dt == torch.float32 else 5e-3)
     assert rel_l2(dg.cpu(), gr.grad) < 1e-5
     assert rel_l2(db.cpu(), br.grad) < 1e-5
+    # the form that also accumulates the column sums of dy (the bias gradient of the Linear in front of the norm), on top of a
+    # non-zero buffer; C = 1536 takes the three-kernel path behind the same entry point
+    dy2 = torch.empty(rows, C, device="cuda", dtype=dt)
+    dg2, db2, dp = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda"), torch.full((C,), 0.5, device="cuda")
+    ops.layernorm_bwd(dev(dout), dev(y), dev(g), mean, rstd, dy=dy2, dgamma=dg2, dbeta=db2, dprev_bias=dp)
+    assert rel_l2(dy2.float().cpu(), yr.grad) < (1e-5 if dt == torch.float32 else 5e-3)
+    assert rel_l2(dg2.cpu(), gr.grad) < 1e-5 and rel_l2(db2.cpu(), br.grad) < 1e-5
+    want = 0.5 + yr.grad.sum(0)  # (dy sums to ~0 along a row, not along a column)
+    assert float((dp.cpu() - want).abs().max()) <= (1e-4 if dt == torch.float32 else 2e-2) * float(want.abs().max() + 1)
 
 
 # ------------------------------------------------------------------------------------------ T5 attention
