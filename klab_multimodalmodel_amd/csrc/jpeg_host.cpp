@@ -158,7 +158,7 @@ int parse(const uint8_t* data, size_t n, Parsed& P, int16_t* coefs) {
     const uint8_t* s = p + 2;
     const uint8_t* se = p + len;
     if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
-      if (len < 8) return KLAB_ERR_BADARG;
+      if (len < 8 || P.have_sof) return KLAB_ERR_BADARG;  // (a second frame header would change the geometry the caller sized its buffer for)
       P.progressive = (m == 0xC2);
       P.precision = s[0];
       P.height = rd16(s + 1);

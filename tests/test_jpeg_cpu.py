@@ -59,3 +59,54 @@ def test_header_info_and_unsupported_files():
     img.save(buf, "JPEG", quality=80)
     cut = buf.getvalue()[:len(buf.getvalue()) // 2]
     ops.jpeg_entropy_decode_batch([cut])
+
+
+def test_host_decoder_survives_mutated_files(tmp_path):
+    """the host stage parses bytes from disk: an AddressSanitizer + UBSan build of csrc/jpeg_host.cpp is run over ~1500 corrupted
+    variants of valid files (bit flips, truncations, spliced segments, inflated dimensions); it may reject them, never touch memory
+    outside its buffers"""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no host compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "jpeg_fuzz"
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", f"-I{root}/include",
+           f"{root}/klab_multimodalmodel_amd/csrc/jpeg_host.cpp", f"{root}/tests/jpeg_fuzz_main.cpp", "-o", str(exe), "-lpthread"]
+    subprocess.run(cmd, check=True, capture_output=True)
+    rng = np.random.default_rng(1234)
+    seeds = [d for n, d in jpeg_cases() if any(k in n for k in ("37x53", "8x8", "restart", "grey_9x9", "prog_420_64x64", "prog_grey", "optimize"))]
+    files = []
+    k = 0
+    for d in seeds:
+        arr = np.frombuffer(d, np.uint8)
+        for _ in range(40):
+            m = arr.copy()
+            kind = rng.integers(0, 5)
+            if kind == 0:    # a few random byte substitutions anywhere
+                for _j in range(int(rng.integers(1, 6))):
+                    m[rng.integers(0, len(m))] = rng.integers(0, 256)
+            elif kind == 1:  # truncation
+                m = m[:int(rng.integers(2, len(m)))]
+            elif kind == 2:  # damage concentrated in the headers (markers, lengths, table definitions, frame / scan headers)
+                for _j in range(int(rng.integers(1, 4))):
+                    m[rng.integers(2, min(len(m), 700))] = rng.integers(0, 256)
+            elif kind == 3:  # a slice of the file spliced in somewhere else
+                a, b = sorted(rng.integers(0, len(m), 2))
+                at = int(rng.integers(0, len(m)))
+                m = np.concatenate([m[:at], m[a:b], m[at:]])
+            else:            # a second frame header with other dimensions / sampling pasted behind the first
+                i = d.find(b"\xff\xc0") if b"\xff\xc0" in d else d.find(b"\xff\xc2")
+                ln = (d[i + 2] << 8) | d[i + 3]
+                sof = bytearray(d[i:i + 2 + ln])
+                sof[5:9] = bytes([0x03, 0xe8, 0x03, 0xe8])  # 1000 x 1000
+                at = i + 2 + ln
+                m = np.concatenate([m[:at], np.frombuffer(bytes(sof), np.uint8), m[at:]])
+            f = tmp_path / f"m{k}.jpg"
+            f.write_bytes(m.tobytes())
+            files.append(str(f))
+            k += 1
+    assert len(files) > 1000
+    for i in range(0, len(files), 400):
+        r = subprocess.run([str(exe)] + files[i:i + 400], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
