@@ -14,7 +14,8 @@ reference effectively does) and normalisation (`csrc/image_pre.hip`).  Entry poi
                                                 replaces loader.py:15-16 as well (use `DatasetLoader(decode_only=True)`)
     GpuImageProcessor().from_jpeg(files)        list of JPEG files (paths or bytes): replaces `Image.open(path).convert('RGB')` too.
                                                 Baseline and progressive Huffman files; a CMYK, 12-bit or arithmetic-coded file
-                                                raises NotImplementedError (decode that one with PIL and pass it to from_decoded)
+                                                raises NotImplementedError unless `other_formats="host"` is passed (then exactly
+                                                those files are decoded with PIL and resized on the device like the rest)
 
 Both return {"pixel_values": cuda float32 [B, 3, 224, 224]} -- what `MyModel.forward` takes.  No CPU fallback: without the HIP
 library the call raises.
@@ -149,8 +150,13 @@ class GpuImageProcessor:
                              std=self.std)
         return BatchFeature(pixel_values=pv)
 
-    def from_jpeg(self, files, n_threads=None):
-        """list of JPEG files (paths, bytes or binary file objects) -> pixel_values; `Image.open(f).convert('RGB')` + from_decoded"""
+    def from_jpeg(self, files, n_threads=None, other_formats="raise"):
+        """list of image files (paths, bytes or binary file objects) -> pixel_values; `Image.open(f).convert('RGB')` + from_decoded.
+        Files the device decoder does not take (CMYK / 12-bit / arithmetic-coded JPEG, PNG, ...): other_formats="raise" (default)
+        raises NotImplementedError naming them; other_formats="host" -- an explicit request, never a silent fallback -- decodes
+        exactly those files with PIL on the host and sends them through the same device resize (`from_decoded`)."""
+        if other_formats not in ("raise", "host"):
+            raise ValueError("other_formats must be 'raise' or 'host'")
         datas = []
         for f in files:
             if isinstance(f, (bytes, bytearray, memoryview)):
@@ -163,10 +169,29 @@ class GpuImageProcessor:
         if n_threads is None:
             import os
             n_threads = min(16, os.cpu_count() or 1)
-        rgb, desc, items = ops.jpeg_decode_pipelined(datas, self.device, n_threads)
         n = len(datas)
+        dev_idx, host_idx = list(range(n)), []
+        if other_formats == "host":
+            dev_idx = []
+            for i, d in enumerate(datas):
+                try:
+                    ok = bool(ops.jpeg_read_info(d).supported)
+                except ValueError:  # not a JPEG stream at all
+                    ok = False
+                (dev_idx if ok else host_idx).append(i)
         pv = self._out(n)
-        ops.image_preprocess(rgb, desc, n, max(it.info.height for it in items), max(it.info.width for it in items), pv, mid=self.loader_size,
-                             out=self.size, filter_a=self.loader_resample, filter_b=self.resample, rescale=self.rescale, mean=self.mean,
-                             std=self.std)
+        if dev_idx:
+            sub = [datas[i] for i in dev_idx]
+            rgb, desc, items = ops.jpeg_decode_pipelined(sub, self.device, n_threads)
+            out = pv if not host_idx else self._out(len(sub))
+            ops.image_preprocess(rgb, desc, len(sub), max(it.info.height for it in items), max(it.info.width for it in items), out,
+                                 mid=self.loader_size, out=self.size, filter_a=self.loader_resample, filter_b=self.resample,
+                                 rescale=self.rescale, mean=self.mean, std=self.std)
+            if host_idx:
+                pv[torch.tensor(dev_idx, device=self.device)] = out
+        if host_idx:
+            import io
+            from PIL import Image
+            dec = self.from_decoded([Image.open(io.BytesIO(datas[i])).convert("RGB") for i in host_idx])["pixel_values"]
+            pv[torch.tensor(host_idx, device=self.device)] = dec
         return BatchFeature(pixel_values=pv)

@@ -84,3 +84,11 @@ def test_from_jpeg_equals_from_decoded():
     Image.fromarray(rng.integers(0, 255, (32, 32, 3), dtype=np.uint8)).convert("CMYK").save(cmyk, "JPEG")
     with pytest.raises(NotImplementedError):
         proc.from_jpeg([cmyk.getvalue()])
+    # the explicit host route for exactly the files the device decoder does not take (here: CMYK JPEG, PNG), in batch order
+    png = io.BytesIO()
+    Image.fromarray(rng.integers(0, 255, (50, 70, 3), dtype=np.uint8)).save(png, "PNG")
+    mixed = [datas[0], cmyk.getvalue(), datas[2], png.getvalue()]
+    c = proc.from_jpeg(mixed, other_formats="host")["pixel_values"]
+    d = proc.from_decoded([Image.open(io.BytesIO(x)).convert("RGB") for x in mixed])["pixel_values"]
+    torch.cuda.synchronize()
+    assert torch.equal(c, d)

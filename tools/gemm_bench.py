@@ -64,6 +64,32 @@ LARGE = [  # BASELINE configs[4] (T5-large d=1024, ff=4096, inner=1024; encoder 
 ]
 
 
+CFG3 = [  # BASELINE configs[2] trainable Swin-V2 (C=96, B=32): stage 0 = 100352 tokens, stage 1 = 25088, stage 2 = 6272
+    ("S0 qkv fwd", 100352, 288, 96, True, True, False),
+    ("S0 proj fwd", 100352, 96, 96, True, True, False),
+    ("S0 fc1 fwd", 100352, 384, 96, True, True, False),
+    ("S0 fc2 fwd", 100352, 96, 384, True, True, False),
+    ("S0 qkv dgrad", 100352, 96, 288, True, False, False),
+    ("S0 proj dgrad", 100352, 96, 96, True, False, False),
+    ("S0 fc1 dgrad", 100352, 96, 384, True, False, False),
+    ("S0 fc2 dgrad", 100352, 384, 96, True, False, False),
+    ("S1 qkv fwd", 25088, 576, 192, True, True, False),
+    ("S1 fc1 fwd", 25088, 768, 192, True, True, False),
+    ("S1 fc2 fwd", 25088, 192, 768, True, True, False),
+    ("S1 fc1 dgrad", 25088, 192, 768, True, False, False),
+    ("S1 fc2 dgrad", 25088, 768, 192, True, False, False),
+    ("S2 qkv fwd", 6272, 1152, 384, True, True, False),
+    ("S2 proj fwd", 6272, 384, 384, True, True, False),
+    ("S2 fc1 fwd", 6272, 1536, 384, True, True, False),
+    ("S2 fc2 fwd", 6272, 384, 1536, True, True, False),
+    ("S2 qkv dgrad", 6272, 384, 1152, True, False, False),
+    ("S2 fc1 dgrad", 6272, 384, 1536, True, False, False),
+    ("S2 fc2 dgrad", 6272, 1536, 384, True, False, False),
+    ("S3 fc1 fwd", 1568, 3072, 768, True, True, False),
+    ("S3 fc2 dgrad", 1568, 3072, 768, True, False, False),
+]
+
+
 def main():
     dt = torch.bfloat16
     tot = 0.0
@@ -71,6 +97,8 @@ def main():
     shapes = SHAPES
     if flt and flt[0] == "--large":
         shapes, flt = LARGE, flt[1:]
+    elif flt and flt[0] == "--cfg3":
+        shapes, flt = CFG3, flt[1:]
     for name, M, N, K, ak, bk, atomic in shapes:
         if flt and not any(f in name for f in flt):
             continue
@@ -91,7 +119,8 @@ def main():
         us = e0.elapsed_time(e1) / n * 1e3
         tf = 2.0 * M * N * K / (us * 1e-6) / 1e12
         tot += us
-        print(f"{name:14s} M={M:6d} N={N:6d} K={K:6d}  {us:9.1f} us  {tf:8.1f} TF/s")
+        gbs = (M * K + N * K + M * N * (4 if atomic else 2) / 2 * 2 / 2) * 2 / (us * 1e-6) / 1e9 if not atomic else 0.0
+        print(f"{name:14s} M={M:6d} N={N:6d} K={K:6d}  {us:9.1f} us  {tf:8.1f} TF/s  {gbs:7.0f} GB/s (operands + output once)")
     print("sum us", tot)
 
 
