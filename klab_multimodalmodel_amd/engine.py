@@ -7,7 +7,7 @@ caller-owned torch storage (parameters, flat gradient buffers, one workspace) to
 """
 import ctypes as C
 import math
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
 import torch

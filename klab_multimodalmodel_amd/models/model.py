@@ -9,7 +9,7 @@ transformer.parameters())`, `model.module.transformer.train()/eval()`, `loss.ite
 `loss.backward()`, `model.module.save(...)`.
 """
 import os
-from typing import Dict, List, Optional
+from typing import Dict, List
 
 import torch
 from torch import nn

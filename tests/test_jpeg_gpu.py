@@ -36,7 +36,6 @@ def test_device_decode_is_pillow_exact():
 def test_device_decode_matches_oracle_on_synthetic_coefficients():
     """coefficients no encoder would write (full int16-safe range, dense high frequencies): the range-limit wrap and the 64-bit
     intermediate arithmetic, device vs oracle"""
-    from klab_multimodalmodel_amd import _lib as L
     from klab_multimodalmodel_amd import ops
     from oracle import jpeg_oracle
     from PIL import Image

@@ -1,5 +1,5 @@
 """Vendor reference point: torch.matmul (hipBLASLt) on the LM-head / T5 GEMM shapes of BASELINE configs[1], to compare with tools/gemm_bench.py."""
-import torch, time
+import torch
 torch.manual_seed(0)
 for (M,N,K,name) in [(4096,32128,512,"lmhead fwd"),(4096,512,32128,"lmhead dgrad"),(32128,512,4096,"lmhead wgrad"),(4096,2048,512,"wi fwd"),(4096,512,2048,"wo fwd")]:
     a=torch.randn(M,K,device="cuda",dtype=torch.bfloat16); b=torch.randn(N,K,device="cuda",dtype=torch.bfloat16)
