@@ -604,7 +604,7 @@ def test_swin_cpb_bias(ops, w, H):
 
 # ------------------------------------------------------------------------------------------ glue
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("rows,V", [(21, 384), (64, 32128), (5, 512)])
+@pytest.mark.parametrize("rows,V", [(21, 384), (64, 32128), (5, 512), (9, 16384), (7, 16392), (3, 32768), (3, 40000)])
 def test_cross_entropy(ops, dt, rows, V):
     logits = rnd(rows, V, seed=1, scale=3.0).to(dt)
     labels = torch.randint(0, V, (rows,), generator=torch.Generator().manual_seed(3))
