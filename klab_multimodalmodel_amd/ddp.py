@@ -30,8 +30,12 @@ class SegmentReducer:
     Device-agnostic so that the bucket logic is testable with gloo on CPU; on GPU the collectives run on `comm_stream`."""
 
     def __init__(self, segments: List[Tuple[str, int, int]], process_group=None, max_bucket_elems: int = 64 << 20,
-                 engine=None, min_bucket_elems: int = 6 << 20):
+                 engine=None, min_bucket_elems: int = 6 << 20, short_tail: bool = False):
         self.segments = segments
+        # short_tail: the LAST layer bucket of a segment always travels alone.  Only the all-reduce issued after the segment's last
+        # layer is exposed (everything earlier runs underneath the layers still in backward), so that message should be as small
+        # as the layer granularity allows instead of whatever the min_bucket merge left over.
+        self.short_tail = bool(short_tail)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.max_bucket = max_bucket_elems
@@ -73,7 +77,8 @@ class SegmentReducer:
         i = 0
         while i < len(layer):  # merge consecutive ready buckets (they are adjacent, descending in memory) up to min_bucket
             lo, hi, j = layer[i][0], layer[i][0] + layer[i][1], i
-            while hi - lo < self.min_bucket and j + 1 < len(layer) and layer[j + 1][0] + layer[j + 1][1] == lo:
+            while (hi - lo < self.min_bucket and j + 1 < len(layer) and layer[j + 1][0] + layer[j + 1][1] == lo
+                   and not (self.short_tail and j + 1 == len(layer) - 1 and len(layer) > 1)):
                 j += 1
                 lo = layer[j][0]
             if not (off <= lo and hi <= off + ln):
@@ -171,7 +176,8 @@ class DistributedDataParallel(nn.Module):
         self.device_ids = device_ids
         eng = module._engine
         nseg = 3 if module.args.image_model_train else 2
-        self.reducer = SegmentReducer(eng.segments[:nseg], process_group, max_bucket_elems, engine=eng, min_bucket_elems=min_bucket_elems)
+        self.reducer = SegmentReducer(eng.segments[:nseg], process_group, max_bucket_elems, engine=eng, min_bucket_elems=min_bucket_elems,
+                                      short_tail=True)
         self._nseg = nseg
         if hasattr(eng, "set_bucket_events"):  # per-layer ready events: only worth recording when collectives will be issued
             eng.set_bucket_events(dist.is_initialized())

@@ -140,6 +140,9 @@ def _wrapper_worker(rank, world, port, q):
             # for the later event
             red2 = type(ddp.reducer)(m._engine.segments, None, engine=m._engine, min_bucket_elems=100)
             ok = ok and red2.plan(0)[0] == ("main", 140, 120, 1)
+            # short_tail (what the wrapper uses): the segment's last layer bucket is never merged -- it is the only exposed message
+            red3 = type(ddp.reducer)(m._engine.segments, None, engine=m._engine, min_bucket_elems=100, short_tail=True)
+            ok = ok and red3.plan(0)[:2] == [("main", 200, 60, 0), ("main", 140, 60, 1)]
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
