@@ -193,12 +193,19 @@ def main():
     dist_on = world > 1 or os.environ.get("KLAB_BENCH_FORCE_DIST") in ("1", "2")  # the latter: rehearse the N>1 code path with one rank
     if a.gpus != world and dist_on:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal knobs (never set by the driver): KLAB_BENCH_DEVICE pins every rank to one card and KLAB_BENCH_BACKEND=gloo moves the
+    # collectives through the host, so that the N > 1 code path (ranks, barrier, reducer, rank-0 JSON) can run on a one-GPU box
+    dev_index = int(os.environ.get("KLAB_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("KLAB_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from klab_multimodalmodel_amd.models.model import MyModel
     sw, t5 = workload_configs(a.workload)
@@ -209,7 +216,7 @@ def main():
     ddp = None
     if dist_on and os.environ.get("KLAB_BENCH_FORCE_DIST") != "2":  # "2": process group without the wrapper (diagnostic)
         from klab_multimodalmodel_amd.ddp import DistributedDataParallel as DDP
-        model = ddp = DDP(model, device_ids=[local_rank],
+        model = ddp = DDP(model, device_ids=[dev_index],
                           overlap_optimizer=(a.optimizer == "klab" and os.environ.get("KLAB_BENCH_OVERLAP_OPT", "1") == "1"))
         core = model.module
     else:
@@ -264,6 +271,13 @@ def main():
     probes = [eng.probe_read(ch) for ch in (0, 1)]
     eng.probe_enable(False)
     lossv = float(loss.item())
+    in_sync = None
+    if dist_on:  # (outside the timed region) after K optimizer steps every replica must hold the same weights
+        chk = torch.stack([p.detach().double().sum() for p in core.transformer.parameters()]).sum().view(1)
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        in_sync = bool(lo.item() == hi.item())
 
     if rank == 0:
         peak = PEAK_FP8_TFLOPS if a.dtype == "fp8" else PEAK_BF16_TFLOPS
@@ -286,7 +300,8 @@ def main():
             st = ddp.reducer.stats()
             out["config"]["rccl"] = {"ranks": dist.get_world_size(), "backend": dist.get_backend(),
                                      "allreduce_calls_per_step": round(st["calls"] / max(a.steps, 1), 2),
-                                     "allreduce_bytes_per_step": int(st["bytes"] / max(a.steps, 1))}
+                                     "allreduce_bytes_per_step": int(st["bytes"] / max(a.steps, 1)),
+                                     "replicas_in_sync_after_run": in_sync}
         # roofline of the kernels that hold the largest shares of GPU time (profiles/*_kernel_stats.csv): live HIP-event
         # durations around each launch on the stream it runs on; algorithmic FLOPs = 2*M*N*K per product
         rl = []
