@@ -1019,6 +1019,229 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(GemmP p, Fp8Scales sc) {
   staged_epilogue<bf16_t, BM, BN, MI, NI>(p, acc, alpha, smem, bm0, bn0, wm, wn, tid, lane);
 }
 
+
+// ---- fp8 on the LDS-DMA ring ------------------------------------------------------------------------------------------------
+// The K-major LDS image of the bf16 kernels is byte-wise: 64-byte rows, 16-byte chunks XOR-swizzled by the source address.  With
+// e4m3 operands a row holds 64 k values; a lane's ds_read_b128 returns 16 consecutive k of its row (chunk c = lane >> 4), which
+// feed TWO v_mfma_f32_16x16x32_fp8_fp8: the low 8 bytes of both operands, then the high 8 bytes.  The first instruction therefore
+// contracts k in {16 g + 0..7}, the second k in {16 g + 8..15} (g = 0..3): together all 64, each once, and since A and B use the
+// same assignment the sum is the dot product.  Same ring, same waits, same hand schedule as gemm_glds_body; half the L2 -> LDS
+// bytes per FLOP, which is what bounds these products.
+template <int ROWS>
+struct GldsOperand8 {
+  static constexpr int L = ROWS / 64, BYTES = ROWS * 64, NF = ROWS / 32, RPF = 1;
+  const char* src[L];
+  unsigned foff[1];
+  __device__ __forceinline__ void init(const char* base, long ld, int row0, int nrows, int wave, int lane, int wrow0) {
+    const int lrow = lane >> 2, lpos = lane & 3;
+    const int lchunk = lpos ^ (((lrow >> 2) & 1) << 1);
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      int r = row0 + (wave * L + i) * 16 + lrow;
+      r = r < nrows ? r : nrows - 1;
+      src[i] = base + (long)r * ld + lchunk * 16;
+    }
+    const int fr = lane & 15, fc = lane >> 4;
+    foff[0] = (unsigned)((wrow0 + fr) * 64 + ((fc ^ (((fr >> 2) & 1) << 1)) * 16));
+  }
+  __device__ __forceinline__ void issue1(int i, int kt, char* stage, int wave) const {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (long)kt * 64),
+                                     (__attribute__((address_space(3))) void*)(stage + (wave * L + i) * 1024), 16, 0, 0);
+  }
+  template <int R, int SOFF>
+  __device__ __forceinline__ void read1(unsigned sbase, u32x4 (&fr)[NF]) const {
+    fr[R] = lds_read_b128<SOFF + R * 1024>(sbase + foff[0]);
+  }
+};
+// both halves in ONE asm statement: the compiler sees a single use of the two 128-bit registers and cannot place a copy of an
+// asm-loaded (not yet landed) register between the LDS read and its wait
+__device__ __forceinline__ void mfma_fp8_asm2(f32x4& acc, const u32x4& x, const u32x4& y) {
+  asm volatile("v_mfma_f32_16x16x32_fp8_fp8 %0, %1, %2, %0\n\tv_mfma_f32_16x16x32_fp8_fp8 %0, %3, %4, %0"
+               : "+v"(acc)
+               : "v"(__builtin_shufflevector(x, x, 0, 1)), "v"(__builtin_shufflevector(y, y, 0, 1)), "v"(__builtin_shufflevector(x, x, 2, 3)),
+                 "v"(__builtin_shufflevector(y, y, 2, 3)));
+}
+
+template <int BM, int BN>
+__device__ __forceinline__ void gemm_glds_fp8_body(const GemmP& p, const Fp8Scales& sc, const int bid = blockIdx.x) {
+  typedef bf16_t T;  // output / epilogue element type
+  constexpr bool ATOMIC = false;
+  constexpr int BK = 64, S = KLAB_GLDS_STAGES;  // a k-tile is still 64 BYTES per row: 64 e4m3 values
+  static_assert(S == 4, "the steady-state loop is unrolled over a 4-stage ring");
+  constexpr int WTM = BM / 2, WTN = BN / 2, MI = WTM / 16, NI = WTN / 16;
+  typedef GldsOperand8<BM> OA;
+  typedef GldsOperand8<BN> OB;
+  constexpr int ABYTES = OA::BYTES, STAGE = OA::BYTES + OB::BYTES;
+  constexpr int LPS = OA::L + OB::L;                    // LDS-DMA instructions per wave per stage
+  constexpr int NRA = MI * OA::RPF, NRB = NI * OB::RPF;  // LDS read instructions per wave per k-tile
+  constexpr int NMMA = MI * NI, NOTH = NRA + NRB + LPS;
+  static_assert(S * STAGE <= 65536, "immediate LDS offsets");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = (wave >> 1) * WTM, wn = (wave & 1) * WTN;
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  const int tile = bid % tiles, split = bid / tiles;
+  int bm0, bn0;
+  tile_of_block(p, BM, BN, tile, bm0, bn0);
+  const int nt_all = p.K / BK;
+  const int per = (nt_all + p.splits - 1) / p.splits;
+  const int kt0 = split * per, kt1 = (kt0 + per < nt_all) ? kt0 + per : nt_all;
+  const int nt = kt1 - kt0;
+  if (nt <= 0) return;
+
+  OA oa; OB ob;
+  oa.init(reinterpret_cast<const char*>(p.A), p.lda, bm0, p.M, wave, lane, wm);
+  ob.init(reinterpret_cast<const char*>(p.B), p.ldb, bn0, p.N, wave, lane, wn);
+  // k-tiles are visited in a per-workgroup rotated order: workgroups that share an A or B panel start together,
+  // and in lockstep they would all hit the same few L2 channels at once; rotating by the tile coordinates spreads
+  // each panel's readers over its whole K extent (only the fp32 summation order changes).
+  const int skew = ((bm0 / BM) * 5 + (bn0 / BN) * 3) % nt;
+  auto ktile = [&](int t) { int kk = t + skew; return kt0 + (kk >= nt ? kk - nt : kk); };
+  const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 a0[MI], b0[NI], a1[MI], b1[NI];
+
+  // "other" operation o of a step: first the LDS reads of the next k-tile (early, so they have the rest of the step to
+  // land), then the LDS-DMA instructions.  SN = ring slot of the k-tile being read, SD = slot being refilled.
+#define KLAB_OTHER(O, SN, SD, NA, NB, DO_DMA, KT)                                                          \
+  if constexpr ((O) < NRA) oa.template read1<(O), (SN) * STAGE>(sbase, NA);                                \
+  else if constexpr ((O) < NRA + NRB) ob.template read1<(O) - NRA, (SN) * STAGE + ABYTES>(sbase, NB);       \
+  else if (DO_DMA) {                                                                                       \
+    constexpr int d = (O) - NRA - NRB;                                                                     \
+    if constexpr (d < OA::L) oa.issue1(d, KT, smem + (SD) * STAGE, wave);                                  \
+    else ob.issue1(d - OA::L, KT, smem + (SD) * STAGE + ABYTES, wave);                                     \
+  }
+  // MFMAs of the current fragments (CA, CB) with the other operations spread between them
+  auto mma_and = [&](auto sn_c, auto sd_c, const u32x4 (&ca)[MI], const u32x4 (&cb)[NI], u32x4 (&na)[MI], u32x4 (&nb)[NI],
+                     bool do_read, bool do_dma, int kt) {
+    constexpr int SN = decltype(sn_c)::value, SD = decltype(sd_c)::value;
+    auto other = [&](auto oc) {
+      constexpr int O = decltype(oc)::value;
+      if constexpr (O < NRA + NRB) { if (do_read) { KLAB_OTHER(O, SN, SD, na, nb, false, kt) } }
+      else { KLAB_OTHER(O, SN, SD, na, nb, do_dma, kt) }
+    };
+    auto unroll_other = [&](auto kc) {  // operations [k*NOTH/NMMA, (k+1)*NOTH/NMMA)
+      constexpr int k = decltype(kc)::value, lo = k * NOTH / NMMA, hi = (k + 1) * NOTH / NMMA;
+      if constexpr (hi - lo > 0) other(std::integral_constant<int, lo>{});
+      if constexpr (hi - lo > 1) other(std::integral_constant<int, lo + 1>{});
+      if constexpr (hi - lo > 2) other(std::integral_constant<int, lo + 2>{});
+      if constexpr (hi - lo > 3) other(std::integral_constant<int, lo + 3>{});
+      static_assert(hi - lo <= 4, "at most four slotted operations per MFMA gap");
+    };
+    auto one = [&](auto kc) {
+      constexpr int k = decltype(kc)::value, i = k / NI, j = k % NI;
+      mfma_fp8_asm2(acc[i][j], cb[j], ca[i]);
+      unroll_other(kc);
+    };
+    [&]<int... Ks>(std::integer_sequence<int, Ks...>) { (one(std::integral_constant<int, Ks>{}), ...); }(std::make_integer_sequence<int, NMMA>{});
+  };
+
+  // prologue: k-tiles 0 .. S-1 fill the whole ring, the fragments of k-tile 0 come in
+#pragma unroll
+  for (int t = 0; t < S; ++t)
+    if (t < nt) {
+#pragma unroll
+      for (int d = 0; d < OA::L; ++d) oa.issue1(d, ktile(t), smem + t * STAGE, wave);
+#pragma unroll
+      for (int d = 0; d < OB::L; ++d) ob.issue1(d, ktile(t), smem + t * STAGE + ABYTES, wave);
+    }
+  wait_groups<LPS>((nt < S ? nt : S) - 1);  // k-tile 0 has landed
+  __builtin_amdgcn_s_barrier();
+  [&]<int... Rs>(std::integer_sequence<int, Rs...>) { (oa.template read1<Rs, 0>(sbase, a0), ...); }(std::make_integer_sequence<int, NRA>{});
+  [&]<int... Rs>(std::integer_sequence<int, Rs...>) { (ob.template read1<Rs, ABYTES>(sbase, b0), ...); }(std::make_integer_sequence<int, NRB>{});
+
+  int t = 0;
+  // one pipeline step on k-tile t held in (CA, CB) = ring slot SC: once every wave has its fragments of t in registers
+  // (lgkmcnt + barrier) slot SC is refilled with k-tile t+S, while k-tile t+1 (slot SC+1) is read into (NA, NB)
+#define KLAB_STEP(SC, CA, CB, NA, NB)                                                                                  \
+  {                                                                                                                   \
+    wait_lgkmcnt<0>();              /* fragments of k-tile t (issued one step ago) */                                  \
+    wait_vmcnt<(S - 2) * LPS>();    /* k-tile t+1 landed; S-2 younger groups stay in flight */                         \
+    __builtin_amdgcn_s_barrier();   /* t+1 visible to all waves; all waves hold k-tile t in registers: slot SC is free */ \
+    mma_and(std::integral_constant<int, ((SC) + 1) % S>{}, std::integral_constant<int, (SC)>{}, CA, CB, NA, NB, true, true, ktile(t + S)); \
+    ++t;                                                                                                              \
+  }
+  while (t + S + 3 < nt) {  // four straight-line steps: every step still has a k-tile to issue
+    KLAB_STEP(0, a0, b0, a1, b1)
+    KLAB_STEP(1, a1, b1, a0, b0)
+    KLAB_STEP(2, a0, b0, a1, b1)
+    KLAB_STEP(3, a1, b1, a0, b0)
+  }
+#undef KLAB_STEP
+  // Tail (t is a multiple of S; at most S+3 k-tiles): not pipelined.  Each step reads its own fragments into (a1, b1)
+  // and consumes them at once, so no asm-loaded register is live across a branch: hipcc copies such values at control
+  // flow merges, and a copy placed right behind the asm ds_read would pick the register up before the data lands.
+  auto mma_plain = [&](const u32x4 (&ca)[MI], const u32x4 (&cb)[NI]) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        mfma_fp8_asm2(acc[i][j], cb[j], ca[i]);
+      }
+  };
+#define KLAB_TAIL(SC, FIRST)                                                                                              \
+  {                                                                                                                     \
+    if constexpr (!(FIRST)) {                                                                                           \
+      const int rem = nt - 1 - t;                                                                                       \
+      wait_groups<LPS>(rem < S - 1 ? rem : S - 1); /* k-tile t landed */                                                 \
+      __builtin_amdgcn_s_barrier();               /* ... for every wave */                                              \
+      [&]<int... Rs>(std::integer_sequence<int, Rs...>) { (oa.template read1<Rs, (SC) * STAGE>(sbase, a1), ...); }(std::make_integer_sequence<int, NRA>{});          \
+      [&]<int... Rs>(std::integer_sequence<int, Rs...>) { (ob.template read1<Rs, (SC) * STAGE + ABYTES>(sbase, b1), ...); }(std::make_integer_sequence<int, NRB>{}); \
+    }                                                                                                                   \
+    wait_lgkmcnt<0>();                                                                                                  \
+    if (t + S < nt) {                                                                                                   \
+      __builtin_amdgcn_s_barrier(); /* every wave holds k-tile t in registers: slot SC is free */                        \
+      _Pragma("unroll") for (int d = 0; d < OA::L; ++d) oa.issue1(d, ktile(t + S), smem + (SC) * STAGE, wave);           \
+      _Pragma("unroll") for (int d = 0; d < OB::L; ++d) ob.issue1(d, ktile(t + S), smem + (SC) * STAGE + ABYTES, wave);  \
+    }                                                                                                                   \
+    if constexpr (FIRST) mma_plain(a0, b0); /* prefetched by the prologue or by the last steady step */                  \
+    else mma_plain(a1, b1);                                                                                             \
+    ++t;                                                                                                                \
+  }
+  KLAB_TAIL(0, true)
+  while (t < nt) {
+    KLAB_TAIL(1, false)
+    if (t >= nt) break;
+    KLAB_TAIL(2, false)
+    if (t >= nt) break;
+    KLAB_TAIL(3, false)
+    if (t >= nt) break;
+    KLAB_TAIL(0, false)
+  }
+#undef KLAB_TAIL
+#undef KLAB_OTHER
+  // MFMA results are not interlocked against the v_accvgpr_read of the epilogue when the MFMA is inline asm
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  wait_vmcnt<0>();
+  float alpha = p.alpha;
+  if (p.alpha_dev) alpha *= p.alpha_dev[0];
+  // dequantise: lane owns m = ... + (lane & 15), n = ... + (lane >> 4) * 4 + r  (the bf16 kernels' accumulator layout)
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = bm0 + wm + i * 16 + (lane & 15);
+    const float sam = sc.sa[m < p.M ? m : p.M - 1];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n0 = bn0 + wn + j * 16 + (lane >> 4) * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + r < p.N ? n0 + r : p.N - 1;
+        acc[i][j][r] *= sam * sc.sb[(long)n * sc.sb_stride];
+      }
+    }
+  }
+  __syncthreads();  // all LDS-DMA retired (vmcnt(0) above) and all fragment reads done: LDS is free for the epilogue
+  staged_epilogue<T, BM, BN, MI, NI>(p, acc, alpha, smem, bm0, bn0, wm, wn, tid, lane);
+}
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_glds_fp8_kernel(GemmP p, Fp8Scales sc) { gemm_glds_fp8_body<BM, BN>(p, sc); }
+
 __device__ __forceinline__ uint32_t pack4_fp8(float a, float b, float c, float d) {
   int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
   w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
@@ -1253,6 +1476,28 @@ extern "C" int klab_gemm_fp8(const klab_gemm_args* a, const float* a_row_scale, 
   Fp8Scales sc{a_row_scale, b_row_scale, b_scale_stride};
   hipStream_t s = (hipStream_t)stream;
   auto tiles = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+  // LDS-DMA ring form (whole 64-byte k-tiles, rows the DMA can address): the production path; the register-staged kernels below
+  // take what is left (K % 64 != 0, tiny operands) and remain reachable with KLAB_FP8_GLDS=0
+  static const bool glds_on = [] { const char* e = getenv("KLAB_FP8_GLDS"); return !e || atoi(e) != 0; }();
+  if (glds_on && (p.K % 64) == 0 && p.K >= 64 && p.M >= 16 && p.N >= 16) {
+    p.splits = 1;
+    const int nt = p.K / 64;
+#define FP8_GLDS(BM_, BN_)                                                                                              \
+    {                                                                                                                   \
+      size_t lds = (size_t)(nt < KLAB_GLDS_STAGES ? nt : KLAB_GLDS_STAGES) * (BM_ + BN_) * 64;                          \
+      const size_t epi = (size_t)epilogue_lds_bytes<BM_, BN_>(p.c_f32);                                                 \
+      if (epi > lds) lds = epi;                                                                                         \
+      int rc = ensure_dyn_lds(reinterpret_cast<const void*>(gemm_glds_fp8_kernel<BM_, BN_>), lds);                      \
+      if (rc) return rc;                                                                                                \
+      hipLaunchKernelGGL((gemm_glds_fp8_kernel<BM_, BN_>), dim3((unsigned)tiles(BM_, BN_)), dim3(256), lds, s, p, sc);   \
+      KLAB_LAUNCH_CHECK();                                                                                              \
+      return KLAB_OK;                                                                                                   \
+    }
+    if (tiles(128, 128) >= 240) FP8_GLDS(128, 128)
+    if (tiles(128, 64) >= 240) FP8_GLDS(128, 64)
+    FP8_GLDS(64, 64)
+#undef FP8_GLDS
+  }
   if (tiles(128, 128) >= 240) {
     size_t lds = 2 * (size_t)(128 + 128) * ROWB;
     const size_t epi = (size_t)epilogue_lds_bytes<128, 128>(p.c_f32);

@@ -371,7 +371,8 @@ def test_t5_attention_dropout_fwd_bwd_consistent(ops):
 
 
 # ------------------------------------------------------------------------------------------ fp8 forward GEMM (configs[4])
-@pytest.mark.parametrize("M,N,K", [(300, 200, 128), (4096, 1536, 512), (77, 64, 1024), (512, 32128, 256), (130, 130, 4096)])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 128), (4096, 1536, 512), (77, 64, 1024), (512, 32128, 256), (130, 130, 4096), (4896, 4096, 1024),
+                                   (2048, 1024, 4096), (1000, 384, 64), (333, 96, 192), (640, 128, 48), (20000, 512, 128)])
 def test_fp8_gemm_matches_emulated_quantisation(ops, M, N, K):
     """klab_quant_fp8_rows + klab_gemm_fp8 (OCP e4m3 operands, per-row scales, fp32 accumulation) against the same quantisation
     emulated in torch: products of e4m3 values are exact in fp32, so only the accumulation order differs."""
