@@ -92,6 +92,13 @@ int klab_rmsnorm_fwd(const float* x, const float* w, void* y, int y_dtype, float
 /* backward: dx = dres + rmsnorm'(dy * dropmask_y); dw += ...; dxt = dtype(dx * dropmask_prev)
  * (dxt is the gradient of the previous sub-layer's GEMM output: residual add + dropout of
  * HF/t5:400,141).  dy is indexed through the same row remap as y.                              */
+/* fp8 mode: the norm's bf16 output AND the same rows in OCP e4m3 (y8 [rows, d]) with one dequantisation scale per row --
+ * klab_quant_fp8_rows folded into the kernel that owns the row; bit-identical to norm followed by that pass.  d <= 1024.        */
+int klab_rmsnorm_fwd_q8(const float* x, const float* w, void* y_bf16, float* rstd, void* y8, float* yscale, int rows, int d, float eps,
+                        float drop_p, const uint32_t* seed_dev, uint32_t tag, void* stream);
+int klab_layernorm_fwd_q8(const void* y_bf16, const float* gamma, const float* beta, const float* shortcut, float* out, void* outt_bf16,
+                          float* mean, float* rstd, void* o8, float* oscale, int rows, int C, float eps, void* stream);
+int klab_gelu_fwd_q8(const void* x_bf16, void* y_bf16, void* y8, float* yscale, int rows, int F, void* stream); /* F <= 4096, F % 8 == 0 */
 int klab_rmsnorm_bwd(const float* dy, const float* x, const float* w, const float* rstd, const float* dres, float* dx,
                      void* dxt, int dxt_dtype, float* dw, int rows, int d, int grp, int grp_stride, int off,
                      float p_y, uint32_t tag_y, float p_prev, uint32_t tag_prev, const uint32_t* seed_dev,

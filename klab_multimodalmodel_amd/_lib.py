@@ -58,6 +58,10 @@ SIGNATURES = {
     "klab_adam_step_range": [vp, i32, i64, i64, vp, vp, vp, vp, i32, f32, f32, f32, f32, f32, f32, f32, vp],
     "klab_layernorm_fwd": [vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, f32, i32, i32, i32, f32, vp, u32, vp],
     "klab_layernorm_bwd": [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, u32, vp],
+    "klab_rmsnorm_fwd_q8": [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, vp, u32, vp],
+    "klab_layernorm_fwd_q8": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
+    "klab_gelu_fwd": [vp, vp, i32, i64, vp],
+    "klab_gelu_fwd_q8": [vp, vp, vp, vp, i32, i32, vp],
     "klab_layernorm_bwd_bias": [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, u32, vp],
     "klab_t5_attn_fwd": [C.POINTER(AttnArgs), vp],
     "klab_t5_attn_bwd": [C.POINTER(AttnArgs), vp],

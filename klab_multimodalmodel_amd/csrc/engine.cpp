@@ -113,6 +113,9 @@ struct klab_engine {
   void* w8 = nullptr; float* wscale = nullptr; void* qdesc = nullptr; int n_qdesc = 0; long q_rows = 0;
   void* x8 = nullptr; float* xscale = nullptr; long x8_bytes = 0, xscale_rows = 0;
   void* x8s = nullptr; float* xscales = nullptr; long x8s_bytes = 0, xscales_rows = 0;  // the side stream's own staging (language encoder)
+  // fp8 mode: the staging buffer of stream [0 main / 1 side] currently holds the e4m3 rows of THIS bf16 matrix (written by the norm
+  // kernel that produced it); consumed by the next forward GEMM on that stream, cleared by anything else that writes the staging
+  const void* q8_src[2] = {nullptr, nullptr}; int q8_rows[2] = {0, 0}, q8_k[2] = {0, 0};
   void* cast_desc = nullptr; int n_cast = 0; long cast_total4 = 0;      // trainable GEMM weights (cast every forward)
   void* adam_desc = nullptr; int n_adam = 0; long adam_total4 = 0, adam_split4 = 0;
   // RMS-norm weight gradients of a stack: per-workgroup partials of every norm, folded by one reduction per stack
@@ -630,13 +633,61 @@ int fwd_gemm(const Ctx& c, klab_gemm_args& g, long woffv) {
     float* xs = side ? e->xscales : e->xscale;
     const long cap = side ? e->x8s_bytes : e->x8_bytes, rows = side ? e->xscales_rows : e->xscale_rows;
     if ((long)g.M * g.K <= cap && g.M <= rows) {
-      RC(klab_quant_fp8_rows(g.A, g.lda, g.M, g.K, x8, g.K, xs, c.ws()));
+      const bool have = e->q8_src[side] == g.A && e->q8_rows[side] == g.M && e->q8_k[side] == g.K;  // the norm in front of this Linear already quantised its rows
+      e->q8_src[side] = nullptr;
+      if (!have) RC(klab_quant_fp8_rows(g.A, g.lda, g.M, g.K, x8, g.K, xs, c.ws()));
       klab_gemm_args q = g;
       q.A = x8; q.B = (const char*)e->w8 + woffv;
       return klab_gemm_fp8(&q, xs, e->wscale + woffv / 8, g.K / 8, c.ws());
     }
   }
   return klab_gemm(&g, c.ws());
+}
+
+// T5 RMS-norm in front of a Linear: in fp8 mode the kernel also leaves the rows in e4m3 in the stream's staging buffer
+int rms_fwd_for_linear(const Ctx& c, const float* x, const float* w, void* y, float* rstd, int M, int d, float eps) {
+  klab_engine* e = c.e;
+  static const bool fuse = [] { const char* v = getenv("KLAB_FP8_NORM_QUANT"); return !v || atoi(v) != 0; }();
+  if (e->fp8 && fuse && c.dt == KLAB_BF16 && d <= 1024 && fp8_weight_ok(d)) {
+    const bool side = c.s == e->side;
+    const long cap = side ? e->x8s_bytes : e->x8_bytes, rows = side ? e->xscales_rows : e->xscale_rows;
+    if ((long)M * d <= cap && M <= rows) {
+      RC(klab_rmsnorm_fwd_q8(x, w, y, rstd, side ? e->x8s : e->x8, side ? e->xscales : e->xscale, M, d, eps, 0.f, nullptr, 0, c.ws()));
+      e->q8_src[side] = y; e->q8_rows[side] = M; e->q8_k[side] = d;
+      return 0;
+    }
+  }
+  return klab_rmsnorm_fwd(x, w, y, c.dt, nullptr, rstd, M, d, eps, 0, 0, 0, 0.f, nullptr, 0, c.ws());
+}
+
+// Swin LayerNorm (+ shortcut) / GELU in front of a Linear: the fp8-mode forms that leave the rows in e4m3 as well
+static bool q8_room(const Ctx& c, long M, long K, bool& side) {
+  klab_engine* e = c.e;
+  static const bool fuse = [] { const char* v = getenv("KLAB_FP8_NORM_QUANT"); return !v || atoi(v) != 0; }();
+  side = c.s == e->side;
+  if (!e->fp8 || !fuse || c.dt != KLAB_BF16 || !fp8_weight_ok(K)) return false;
+  return M * K <= (side ? e->x8s_bytes : e->x8_bytes) && M <= (side ? e->xscales_rows : e->xscale_rows);
+}
+int ln_fwd_for_linear(const Ctx& c, const void* y, const float* g, const float* b, const float* shortcut, float* out, void* outt, float* mean,
+                      float* rstd, int M, int C, float eps) {
+  klab_engine* e = c.e;
+  bool side;
+  if (q8_room(c, M, C, side)) {
+    RC(klab_layernorm_fwd_q8(y, g, b, shortcut, out, outt, mean, rstd, side ? e->x8s : e->x8, side ? e->xscales : e->xscale, M, C, eps, c.ws()));
+    e->q8_src[side] = outt; e->q8_rows[side] = M; e->q8_k[side] = C;
+    return 0;
+  }
+  return klab_layernorm_fwd(y, c.dt, g, b, shortcut, out, outt, c.dt, mean, rstd, M, C, eps, 0, 0, 0, 0.f, nullptr, 0, c.ws());
+}
+int gelu_fwd_for_linear(const Ctx& c, const void* z, void* a, int M, int F) {
+  klab_engine* e = c.e;
+  bool side;
+  if (F <= 4096 && !(F & 7) && q8_room(c, M, F, side)) {
+    RC(klab_gelu_fwd_q8(z, a, side ? e->x8s : e->x8, side ? e->xscales : e->xscale, M, F, c.ws()));
+    e->q8_src[side] = a; e->q8_rows[side] = M; e->q8_k[side] = F;
+    return 0;
+  }
+  return klab_gelu_fwd(z, a, c.dt, (long)M * F, c.ws());
 }
 
 // y = x @ W^T   (W [N,K] from the weight arena)
@@ -680,7 +731,7 @@ int t5_stack_forward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Par
     const T5LayerIdx& l = L[i];
     T5LayerBufs& b = s.L[i];
     // --- self attention (HF/t5:372-401) ---
-    RC(klab_rmsnorm_fwd(s.h[j], W[l.ln0], b.xn1, c.dt, nullptr, b.rstd1, M, d, cfg.ln_eps, 0, 0, 0, 0.f, nullptr, 0, c.ws()));
+    RC(rms_fwd_for_linear(c, s.h[j], W[l.ln0], b.xn1, b.rstd1, M, d, cfg.ln_eps));
     RC(linear_fwd(c, b.xn1, M, d, P[l.q].warena_off, 3 * inner, b.qkv, 3 * inner, c.dt));
     {
       klab_attn_args a;
@@ -694,7 +745,7 @@ int t5_stack_forward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Par
     RC(t5_sublayer_out(c, b.ctx, M, inner, P[l.o].warena_off, d, s.h[j], s.h[j + 1], p, tag_of(stack_id, (int)i, SITE_ATTN_OUT)));
     ++j;
     if (dec) {  // --- cross attention (HF/t5:404-432), K/V of all layers projected once ---
-      RC(klab_rmsnorm_fwd(s.h[j], W[l.ln1], b.xn2, c.dt, nullptr, b.rstd2, M, d, cfg.ln_eps, 0, 0, 0, 0.f, nullptr, 0, c.ws()));
+      RC(rms_fwd_for_linear(c, s.h[j], W[l.ln1], b.xn2, b.rstd2, M, d, cfg.ln_eps));
       RC(linear_fwd(c, b.xn2, M, d, P[l.cq].warena_off, inner, b.qc, inner, c.dt));
       klab_attn_args a;
       memset(&a, 0, sizeof(a));
@@ -709,7 +760,7 @@ int t5_stack_forward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Par
       ++j;
     }
     // --- feed forward (HF/t5:83-94,137-141) ---
-    RC(klab_rmsnorm_fwd(s.h[j], W[l.ln2], b.xn3, c.dt, nullptr, b.rstd3, M, d, cfg.ln_eps, 0, 0, 0, 0.f, nullptr, 0, c.ws()));
+    RC(rms_fwd_for_linear(c, s.h[j], W[l.ln2], b.xn3, b.rstd3, M, d, cfg.ln_eps));
     {
       klab_gemm_args g = G0(c, M, ff, d, b.xn3, d, 1, woff(c, P[l.wi].warena_off), d, 1, b.hmid, ff, c.dt);
       g.act = KLAB_ACT_RELU; g.drop_p = p; g.seed_dev = c.e->seed_dev; g.drop_tag = tag_of(stack_id, (int)i, SITE_MID);
@@ -971,12 +1022,11 @@ int swin_forward(const Ctx& c, const float* pixels, float p_in, bool refresh_bia
       if (prc != 0 && prc != KLAB_ERR_UNSUPPORTED) return prc;
       if (prc != 0) {
         RC(linear_fwd(c, q.ctx, M, C, P[ix.pw].warena_off, C, q.po, C, c.dt, W[ix.pb]));
-        RC(klab_layernorm_fwd(q.po, c.dt, W[ix.ln1w], W[ix.ln1b], x, q.h1, q.h1t, c.dt, q.mean1, q.rstd1, M, C, s.ln_eps, 0, 0, 0, 0.f,
-                              nullptr, 0, c.ws()));
+        RC(ln_fwd_for_linear(c, q.po, W[ix.ln1w], W[ix.ln1b], x, q.h1, q.h1t, q.mean1, q.rstd1, M, C, s.ln_eps));
       }
       if (e->cfg.train_swin) {  // keep the pre-activation for gelu'
         RC(linear_fwd(c, q.h1t, M, C, P[ix.f1w].warena_off, F, q.z, F, c.dt, W[ix.f1b]));
-        RC(klab_gelu_fwd(q.z, q.a, c.dt, (long)M * F, c.ws()));
+        RC(gelu_fwd_for_linear(c, q.z, q.a, M, F));
       } else {
         // frozen tower, narrow stage: fc1 + GELU + fc2 + LayerNorm + residual in one kernel (the hidden layer stays on chip)
         static const bool fused_mlp = [] { const char* v = getenv("KLAB_SWIN_FUSED_MLP"); return !v || atoi(v) != 0; }();
@@ -987,8 +1037,7 @@ int swin_forward(const Ctx& c, const float* pixels, float p_in, bool refresh_bia
         RC(linear_fwd(c, q.h1t, M, C, P[ix.f1w].warena_off, F, q.a, F, c.dt, W[ix.f1b], KLAB_ACT_GELU));
       }
       RC(linear_fwd(c, q.a, M, F, P[ix.f2w].warena_off, C, q.fo, C, c.dt, W[ix.f2b]));
-      RC(klab_layernorm_fwd(q.fo, c.dt, W[ix.ln2w], W[ix.ln2b], q.h1, q.h2, q.h2t, c.dt, q.mean2, q.rstd2, M, C, s.ln_eps, 0, 0, 0, 0.f,
-                            nullptr, 0, c.ws()));
+      RC(ln_fwd_for_linear(c, q.fo, W[ix.ln2w], W[ix.ln2b], q.h1, q.h2, q.h2t, q.mean2, q.rstd2, M, C, s.ln_eps));
       x = q.h2; xt = q.h2t;
     }
     if (st < s.n_stages - 1) {

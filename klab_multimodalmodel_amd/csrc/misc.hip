@@ -690,6 +690,61 @@ extern "C" int klab_add_f32(float* y, const float* x, long n, void* stream) {
   return KLAB_OK;
 }
 
+// fp8 mode: a = gelu(z) (bf16) and the same rows in e4m3 with one scale per row (the quantisation pass in front of fc2 folded in);
+// one wave per row of F <= 4096 values
+__global__ __launch_bounds__(256) void gelu_fwd_q8_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, unsigned char* __restrict__ y8,
+                                                          float* __restrict__ yscale, int rows, int F) {
+  constexpr int MAXV = 8;
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xr = x + row * F;
+  bf16x8 v[MAXV];
+  float amax = 0.f;
+#pragma unroll
+  for (int u = 0; u < MAXV; ++u) {
+    const int k = (u * 64 + lane) * 8;
+    if (k < F) {
+      const bf16x8 z = *reinterpret_cast<const bf16x8*>(xr + k);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[u][e] = from_f32<bf16_t>(gelu_for<bf16_t>(to_f32(z[e])));
+        amax = fmaxf(amax, fabsf((float)v[u][e]));
+      }
+      *reinterpret_cast<bf16x8*>(y + row * F + k) = v[u];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+  const float sc = amax > 0.f ? amax * (1.f / 448.f) : 1.f;
+  const float inv = 1.f / sc;
+  if (lane == 0) yscale[row] = sc;
+#pragma unroll
+  for (int u = 0; u < MAXV; ++u) {
+    const int k = (u * 64 + lane) * 8;
+    if (k < F) {
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf((float)v[u][e] * inv, -448.f), 448.f);
+      int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
+      int w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false);
+      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
+      *reinterpret_cast<int2*>(y8 + row * F + k) = int2{w0, w1};
+    }
+  }
+}
+
+extern "C" int klab_gelu_fwd_q8(const void* x, void* y, void* y8, float* yscale, int rows, int F, void* stream) {
+  if (!x || !y || !y8 || !yscale || rows < 0 || F <= 0 || (F & 7)) return KLAB_ERR_BADARG;
+  if (F > 4096) return KLAB_ERR_UNSUPPORTED;
+  if (rows == 0) return KLAB_OK;
+  hipLaunchKernelGGL(gelu_fwd_q8_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y,
+                     (unsigned char*)y8, yscale, rows, F);
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+
 extern "C" int klab_gelu_fwd(const void* x, void* y, int dtype, long n, void* stream) {
   if (!x || !y || (n & 7)) return KLAB_ERR_BADARG;
   hipStream_t s = (hipStream_t)stream;

@@ -64,6 +64,65 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
   }
 }
 
+// RMS-norm forward that ALSO emits the row in OCP e4m3 with its dequantisation scale (fp8 mode: the per-token quantisation pass in
+// front of the next Linear, klab_quant_fp8_rows, folded into the kernel that already owns the row).  Bit-identical to norm followed
+// by the separate pass: the e4m3 value is taken from the bf16-ROUNDED output, amax / 448 is the scale, 1 for an all-zero row.
+template <int SLOTS>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_q8_kernel(const float* __restrict__ x, const float* __restrict__ w, bf16_t* __restrict__ y,
+                                                             float* __restrict__ rstd, unsigned char* __restrict__ y8,
+                                                             float* __restrict__ yscale, int rows, int d, float eps, float p,
+                                                             const uint32_t* seed, uint32_t tag) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const DropCtx dc = make_drop(seed, tag, p);
+  for (long row = (long)blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * wpb) {
+    const float* xr = x + row * d;
+    f32x4 v[SLOTS];
+    float ss = 0.f;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      const int c = lane * 4 + s * 256;
+      v[s] = c < d ? *reinterpret_cast<const f32x4*>(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      ss += v[s][0] * v[s][0] + v[s][1] * v[s][1] + v[s][2] * v[s][2] + v[s][3] * v[s][3];
+    }
+    ss = wave_sum(ss);
+    const float r = rsqrtf(ss / (float)d + eps);
+    if (lane == 0 && rstd) rstd[row] = r;
+    float amax = 0.f;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      const int c = lane * 4 + s * 256;
+      if (c < d) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(w + c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bf16_t o = (bf16_t)(g[i] * (v[s][i] * r) * drop_mult(dc, (uint64_t)row * d + c + i));
+          v[s][i] = (float)o;  // the value the GEMM's bf16 form would read
+          amax = fmaxf(amax, fabsf(v[s][i]));
+        }
+        store4<bf16_t>(y + row * d + c, v[s][0], v[s][1], v[s][2], v[s][3]);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    const float sc = amax > 0.f ? amax * (1.f / 448.f) : 1.f;
+    const float inv = 1.f / sc;
+    if (lane == 0) yscale[row] = sc;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      const int c = lane * 4 + s * 256;
+      if (c < d) {
+        float f[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = fminf(fmaxf(v[s][i] * inv, -448.f), 448.f);
+        int wd = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+        wd = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], wd, true);
+        *reinterpret_cast<int*>(y8 + row * d + c) = wd;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // RMS-norm backward.
 //   dy_eff = dy * dropmult_y            (dropout that followed the norm, if any)
@@ -232,12 +291,13 @@ __global__ __launch_bounds__(256) void rmsnorm_dw_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------
 // LPR = lanes per row (16 for C = 64, 32 for C = 128, 64 otherwise): narrow Swin stage-0/1 rows are packed 4 / 2 per
 // wave so that every lane streams 16 B (with one row per wave, C = 64 kept 16 of 64 lanes busy).
-template <typename TI, typename TO, int LPR>
+template <typename TI, typename TO, int LPR, bool Q8 = false>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const TI* __restrict__ y, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const float* __restrict__ shortcut,
                                                             float* __restrict__ out, TO* __restrict__ outt, float* __restrict__ mean,
                                                             float* __restrict__ rstd, int rows, int C, float eps, int grp,
-                                                            int grp_stride, int off, float p, const uint32_t* seed, uint32_t tag) {
+                                                            int grp_stride, int off, float p, const uint32_t* seed, uint32_t tag,
+                                                            unsigned char* __restrict__ o8 = nullptr, float* __restrict__ oscale = nullptr) {
   constexpr int RPW = 64 / LPR;  // rows per wave
   const int lane = threadIdx.x & 63;
   const int sub = lane / LPR, l = lane % LPR;
@@ -265,6 +325,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const TI* __restrict
     if (!live) continue;
     if (l == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = r; }
     const long orow = remap_row(row, grp, grp_stride, off);
+    float amax = 0.f;
+    (void)amax;
     for (int c = l * 4; c < C; c += LPR * 4) {
       f32x4 v = load4<TI>(yr + c);
       f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
@@ -281,6 +343,41 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const TI* __restrict
       for (int i = 0; i < 4; ++i) o[i] *= drop_mult(dc, (uint64_t)orow * C + c + i);
       if (out) store4<float>(out + orow * C + c, o[0], o[1], o[2], o[3]);
       if (outt) store4<TO>(outt + orow * C + c, o[0], o[1], o[2], o[3]);
+      if constexpr (Q8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) amax = fmaxf(amax, fabsf((float)(bf16_t)o[i]));
+      }
+    }
+    if constexpr (Q8) {
+      // fp8 mode: the same row in e4m3 with its scale (klab_quant_fp8_rows of the bf16 copy, folded in): second sweep over the row
+      // (cache-hot) once the row maximum is known
+#pragma unroll
+      for (int o2 = LPR / 2; o2 > 0; o2 >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o2, 64));
+      const float sc = amax > 0.f ? amax * (1.f / 448.f) : 1.f;
+      const float inv = 1.f / sc;
+      if (l == 0) oscale[orow] = sc;
+      for (int c = l * 4; c < C; c += LPR * 4) {
+        f32x4 v = load4<TI>(yr + c);
+        f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+        f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (v[i] - mu) * r * g[i] + b[i];
+        if (shortcut) {
+          f32x4 q = *reinterpret_cast<const f32x4*>(shortcut + row * C + c);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[i] += q[i];
+        }
+        float f[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          o[i] *= drop_mult(dc, (uint64_t)orow * C + c + i);
+          f[i] = fminf(fmaxf((float)(bf16_t)o[i] * inv, -448.f), 448.f);
+        }
+        int wd = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+        wd = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], wd, true);
+        *reinterpret_cast<int*>(o8 + orow * C + c) = wd;
+      }
     }
   }
 }
@@ -470,6 +567,22 @@ extern "C" int klab_rmsnorm_fwd(const float* x, const float* w, void* y, int y_d
   return KLAB_OK;
 }
 
+// y (bf16) = norm(x) * w, rstd, and y8 / yscale = the same rows in e4m3 with one scale per row (d <= 1024, d % 4 == 0)
+extern "C" int klab_rmsnorm_fwd_q8(const float* x, const float* w, void* y_bf16, float* rstd, void* y8, float* yscale, int rows, int d,
+                                   float eps, float drop_p, const uint32_t* seed_dev, uint32_t tag, void* stream) {
+  if (!x || !w || !y_bf16 || !y8 || !yscale || rows < 0 || d <= 0 || (d & 3)) return KLAB_ERR_BADARG;
+  if (d > 1024) return KLAB_ERR_UNSUPPORTED;
+  if (rows == 0) return KLAB_OK;
+  hipStream_t s = (hipStream_t)stream;
+#define RQ(SL)                                                                                                                         \
+  hipLaunchKernelGGL((rmsnorm_fwd_q8_kernel<SL>), dim3(norm_grid(rows)), dim3(256), 0, s, x, w, (bf16_t*)y_bf16, rstd, (unsigned char*)y8, \
+                     yscale, rows, d, eps, drop_p, seed_dev, tag)
+  if (d <= 256) RQ(1); else if (d <= 512) RQ(2); else RQ(4);
+#undef RQ
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+
 static int rms_part_rows(int rows) {
   static const int nblk = [] { const char* v = getenv("KLAB_RMS_BLOCKS"); int n = v ? atoi(v) : 512; return n < 1 ? 1 : n; }();
   const int g16 = (rows + 15) / 16;
@@ -577,6 +690,26 @@ extern "C" int klab_layernorm_fwd(const void* y, int y_dtype, const float* gamma
   else if (outt_dtype == KLAB_BF16) LN_LAUNCH(float, bf16_t);
   else LN_LAUNCH(float, float);
 #undef LN_LAUNCH
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+
+// fp8 mode: as klab_layernorm_fwd with a bf16 `outt`, plus the same rows in e4m3 (o8 [rows, C]) and one scale per row
+extern "C" int klab_layernorm_fwd_q8(const void* y, const float* gamma, const float* beta, const float* shortcut, float* out, void* outt,
+                                     float* mean, float* rstd, void* o8, float* oscale, int rows, int C, float eps, void* stream) {
+  if (!y || !gamma || !beta || !outt || !o8 || !oscale || rows < 0 || C <= 0 || (C & 3)) return KLAB_ERR_BADARG;
+  if (rows == 0) return KLAB_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int g = norm_grid(rows);
+  if (C <= 64)
+    hipLaunchKernelGGL((layernorm_fwd_kernel<bf16_t, bf16_t, 16, true>), dim3(norm_grid((rows + 3) / 4)), dim3(256), 0, s, (const bf16_t*)y, gamma,
+                       beta, shortcut, out, (bf16_t*)outt, mean, rstd, rows, C, eps, 0, 0, 0, 0.f, nullptr, 0, (unsigned char*)o8, oscale);
+  else if (C <= 128)
+    hipLaunchKernelGGL((layernorm_fwd_kernel<bf16_t, bf16_t, 32, true>), dim3(norm_grid((rows + 1) / 2)), dim3(256), 0, s, (const bf16_t*)y, gamma,
+                       beta, shortcut, out, (bf16_t*)outt, mean, rstd, rows, C, eps, 0, 0, 0, 0.f, nullptr, 0, (unsigned char*)o8, oscale);
+  else
+    hipLaunchKernelGGL((layernorm_fwd_kernel<bf16_t, bf16_t, 64, true>), dim3(g), dim3(256), 0, s, (const bf16_t*)y, gamma, beta, shortcut, out,
+                       (bf16_t*)outt, mean, rstd, rows, C, eps, 0, 0, 0, 0.f, nullptr, 0, (unsigned char*)o8, oscale);
   KLAB_LAUNCH_CHECK();
   return KLAB_OK;
 }

@@ -125,6 +125,34 @@ def swin_mlp_fused(x, shortcut, w1, b1, w2, b2, gamma, beta, out, outt=None, eps
                                     L.stream_ptr()), "klab_swin_mlp_fused")
 
 
+def rmsnorm_fwd_q8(x, w, y, rstd, y8, yscale, eps=1e-6):
+    """fp8 mode: y (bf16) = RMS-norm(x) * w and the same rows in e4m3 (y8 uint8 [rows, d]) with one scale per row"""
+    lib = L.load()
+    rows, d = x.shape
+    L.check(lib.klab_rmsnorm_fwd_q8(x.data_ptr(), w.data_ptr(), y.data_ptr(), L.ptr(rstd), y8.data_ptr(), yscale.data_ptr(), rows, d, eps, 0.0,
+                                    None, 0, L.stream_ptr()), "klab_rmsnorm_fwd_q8")
+
+
+def layernorm_fwd_q8(y, gamma, beta, shortcut, out, outt, mean, rstd, o8, oscale, eps=1e-5):
+    """fp8 mode: klab_layernorm_fwd with a bf16 `outt`, plus the same rows in e4m3 and one scale per row"""
+    lib = L.load()
+    rows, Cc = y.shape
+    L.check(lib.klab_layernorm_fwd_q8(y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), L.ptr(shortcut), L.ptr(out), outt.data_ptr(), L.ptr(mean),
+                                      L.ptr(rstd), o8.data_ptr(), oscale.data_ptr(), rows, Cc, eps, L.stream_ptr()), "klab_layernorm_fwd_q8")
+
+
+def gelu_fwd(z, a):
+    """a = gelu(z), elementwise (the trainable Swin tower keeps the pre-activation z for the backward)"""
+    lib = L.load()
+    L.check(lib.klab_gelu_fwd(z.data_ptr(), a.data_ptr(), L.dtype_code(z.dtype), z.numel(), L.stream_ptr()), "klab_gelu_fwd")
+
+
+def gelu_fwd_q8(z, a, a8, ascale):
+    lib = L.load()
+    rows, F = z.shape
+    L.check(lib.klab_gelu_fwd_q8(z.data_ptr(), a.data_ptr(), a8.data_ptr(), ascale.data_ptr(), rows, F, L.stream_ptr()), "klab_gelu_fwd_q8")
+
+
 def layernorm_bwd(dout, y, gamma, mean, rstd, dy=None, dgamma=None, dbeta=None, grp=0, grp_stride=0, off=0, drop_p=0.0,
                   seed=None, tag=0, dprev_bias=None):
     lib = L.load()

@@ -404,6 +404,53 @@ def test_fp8_gemm_matches_emulated_quantisation(ops, M, N, K):
     assert rel_l2(ref, a.float() @ b.float().t()) < 6e-2
 
 
+@pytest.mark.parametrize("rows,d", [(300, 512), (77, 1024), (4096, 768), (5, 256), (1000, 64)])
+def test_rmsnorm_fwd_with_fused_fp8_rows_equals_norm_then_quantise(ops, rows, d):
+    """fp8 mode folds the per-token quantisation into the RMS-norm kernel: the e4m3 bytes and scales must be IDENTICAL to
+    klab_quant_fp8_rows of the bf16 output the same kernel wrote"""
+    x, w = dev(rnd(rows, d, seed=1, scale=3.0)), dev(1 + 0.2 * rnd(d, seed=2))
+    x[2] = 0  # an all-zero row
+    y0 = torch.empty(rows, d, device="cuda", dtype=torch.bfloat16)
+    r0 = torch.empty(rows, device="cuda")
+    ops.rmsnorm_fwd(x, w, y=y0, rstd=r0)
+    q0, s0 = ops.quant_fp8_rows(y0)
+    y1, r1 = torch.empty_like(y0), torch.empty_like(r0)
+    q1, s1 = torch.empty(rows, d, device="cuda", dtype=torch.uint8), torch.empty(rows, device="cuda")
+    ops.rmsnorm_fwd_q8(x, w, y1, r1, q1, s1)
+    # against the plain kernel: the same values up to the last bit of the row statistic (a different summation order)
+    assert torch.allclose(r0, r1, rtol=2e-6, atol=0) and rel_l2(y1.float().cpu(), y0.float().cpu()) < 1e-3
+    # and exactly what the separate pass makes of the kernel's OWN bf16 output
+    q0, s0 = ops.quant_fp8_rows(y1)
+    assert torch.equal(s0.view(-1), s1) and torch.equal(q0, q1)
+
+
+@pytest.mark.parametrize("rows,C", [(1000, 64), (333, 128), (200, 256), (77, 1024), (50, 96)])
+def test_layernorm_and_gelu_with_fused_fp8_rows_equal_the_separate_pass(ops, rows, C):
+    """fp8 mode, Swin side: LayerNorm (+ shortcut) and GELU emit their rows in e4m3 too; outputs, bytes and scales identical to the
+    plain kernel followed by klab_quant_fp8_rows"""
+    y, g, b = dev(rnd(rows, C, seed=1).to(torch.bfloat16)), dev(1 + 0.1 * rnd(C, seed=2)), dev(0.1 * rnd(C, seed=3))
+    sc = dev(rnd(rows, C, seed=4))
+    out0, outt0 = torch.empty(rows, C, device="cuda"), torch.empty(rows, C, device="cuda", dtype=torch.bfloat16)
+    m0, r0 = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    ops.layernorm_fwd(y, g, b, shortcut=sc, out=out0, outt=outt0, mean=m0, rstd=r0)
+    q0, s0 = ops.quant_fp8_rows(outt0)
+    out1, outt1, m1, r1 = torch.empty_like(out0), torch.empty_like(outt0), torch.empty_like(m0), torch.empty_like(r0)
+    q1, s1 = torch.empty(rows, C, device="cuda", dtype=torch.uint8), torch.empty(rows, device="cuda")
+    ops.layernorm_fwd_q8(y, g, b, sc, out1, outt1, m1, r1, q1, s1)
+    assert torch.equal(out0, out1) and torch.equal(outt0, outt1) and torch.equal(m0, m1) and torch.equal(r0, r1)
+    assert torch.equal(s0.view(-1), s1) and torch.equal(q0, q1)
+    F4 = 4 * C
+    z = dev((2 * rnd(rows, F4, seed=5)).to(torch.bfloat16))
+    z[1] = -30.0  # gelu -> 0 everywhere: the all-zero row
+    a0 = torch.empty_like(z)
+    ops.gelu_fwd(z, a0)
+    qa0, sa0 = ops.quant_fp8_rows(a0)
+    a1 = torch.empty_like(z)
+    qa1, sa1 = torch.empty(rows, F4, device="cuda", dtype=torch.uint8), torch.empty(rows, device="cuda")
+    ops.gelu_fwd_q8(z, a1, qa1, sa1)
+    assert torch.equal(a0, a1) and torch.equal(sa0.view(-1), sa1) and torch.equal(qa0, qa1)
+
+
 # ------------------------------------------------------------------------------------------ Swin attention
 def _swin_attn_ref(qkv, bias, logit_scale, B, R, w, shift, H, C):
     """HF/swinv2:389-455 + :652-690 on a fused qkv [B*R*R, 3C] (fp32 torch)."""
