@@ -825,3 +825,42 @@ def test_swin_qkv_attn_fused_matches_two_kernel_path(ops, R, Cc, Hh, shift):
     out = torch.empty(M, Cc, device="cuda", dtype=torch.bfloat16)
     ops.swin_qkv_attn_fused(dev(x), dev(wq), dev(bq), out, dev(bias), dev(ls), B=B, R=R, w=w, shift=shift, H=Hh, C=Cc)
     assert rel_l2(out.float().cpu(), ref.float().cpu()) < 1.5e-2
+
+
+def test_error_paths_of_the_entry_points_added_in_round_two(ops):
+    """bad arguments and unsupported shapes come back as KLAB_ERR_* (ValueError / NotImplementedError), never as a launch"""
+    import ctypes as C
+    from klab_multimodalmodel_amd import _lib as L
+    lib = L.load()
+    x = torch.zeros(4, 2048, device="cuda")
+    w = torch.ones(2048, device="cuda")
+    y = torch.zeros(4, 2048, device="cuda", dtype=torch.bfloat16)
+    y8 = torch.zeros(4, 2048, device="cuda", dtype=torch.uint8)
+    sc = torch.zeros(4, device="cuda")
+    with pytest.raises(NotImplementedError):  # rows wider than the register-resident form
+        ops.rmsnorm_fwd_q8(x, w, y, None, y8, sc)
+    with pytest.raises(ValueError):
+        L.check(lib.klab_rmsnorm_fwd_q8(x.data_ptr(), w.data_ptr(), None, None, y8.data_ptr(), sc.data_ptr(), 4, 2048, 1e-6, 0.0, None, 0, None), "q8")
+    z = torch.zeros(2, 8192, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(NotImplementedError):
+        ops.gelu_fwd_q8(z, torch.empty_like(z), torch.zeros(2, 8192, device="cuda", dtype=torch.uint8), torch.zeros(2, device="cuda"))
+    with pytest.raises(ValueError):  # the bias-gradient form needs the row result it sums
+        L.check(lib.klab_layernorm_bwd_bias(x.data_ptr(), y.data_ptr(), L.BF16, w.data_ptr(), sc.data_ptr(), sc.data_ptr(), None, None, None,
+                                            w.data_ptr(), 4, 2048, 0, 0, 0, 0.0, None, 0, None), "ln")
+    # JPEG device half: an item the header marked unsupported, and a workspace that is too small
+    items = (L.JpegItem * 1)()
+    items[0].info.width = items[0].info.height = 8
+    items[0].info.ncomp = 1
+    items[0].info.hmax = items[0].info.vmax = 1
+    items[0].info.hs[0] = items[0].info.vs[0] = 1
+    items[0].info.bw[0] = items[0].info.bh[0] = 1
+    items[0].info.coef_blocks = 1
+    buf = torch.zeros(1 << 16, device="cuda", dtype=torch.uint8)
+    args = (buf.data_ptr(), buf.data_ptr(), C.cast(items, C.c_void_p), buf.data_ptr(), 1, buf.data_ptr(), buf.data_ptr())
+    with pytest.raises(NotImplementedError):
+        L.check(lib.klab_jpeg_decode_device(*args, 1 << 16, None), "jpeg")
+    items[0].info.supported = 1
+    with pytest.raises(ValueError):
+        L.check(lib.klab_jpeg_decode_device(*args, 16, None), "jpeg")
+    assert lib.klab_jpeg_decode_ws_bytes(C.cast(items, C.c_void_p), 1) >= 64
+    torch.cuda.synchronize()
