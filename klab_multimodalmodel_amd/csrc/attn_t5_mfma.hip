@@ -135,9 +135,9 @@ __global__ __launch_bounds__(256) void t5_attn_fwd_mfma(AttnMP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = t * 16 + g * 4 + r;
-        float x = s[t][r];
-        if (key < Lk && !(p.causal && key > q)) { if (brow) x += brow[key]; }
-        else x = -INFINITY;
+        // branch-free: the bias read is clamped into the row, an excluded key is replaced by the select
+        float x = s[t][r] + (brow ? brow[key < Lk ? key : Lk - 1] : 0.f);
+        x = (key < Lk && !(p.causal && key > q)) ? x : -INFINITY;
         s[t][r] = x;
         m = fmaxf(m, x);
       }
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void t5_attn_fwd_mfma(AttnMP p) {
   for (int t = 0; t < MAXT; ++t) {
     if (t < NT) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) s[t][r] *= inv * drop_mult32(dc, base + t * 16 + g * 4 + r);
+      for (int r = 0; r < 4; ++r) s[t][r] *= inv * drop_mult32_nb(dc, base + t * 16 + g * 4 + r);
     }
   }
   // O^T[d][q] = sum_key V[key][d] * P[q][key]
@@ -352,13 +352,10 @@ __global__ __launch_bounds__(256) void t5_attn_bwd_mfma(AttnMP p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = t * 16 + g * 4 + r;
-          float dsv = 0.f;
-          if (key < Lk && q < Lq && !(p.causal && key > q)) {
-            const float x = st[r] * sscale + bcur[u][r];
-            const float pr = __expf(x - lq);
-            dsv = pr * (dpt[r] * drop_mult32(dc, (uint32_t)q * (uint32_t)Lk + key) - dq_);
-            if (dbrow) atomicAdd(dbrow + key, dsv);
-          }
+          const bool ok = key < Lk && q < Lq && !(p.causal && key > q);
+          const float pr = ok ? __expf(st[r] * sscale + bcur[u][r] - lq) : 0.f;  // (branch-free: see the forward)
+          const float dsv = pr * (dpt[r] * drop_mult32_nb(dc, (uint32_t)q * (uint32_t)Lk + key) - dq_);
+          if (dbrow) { if (ok) atomicAdd(dbrow + key, dsv); }
           ds2[u][r] = dsv;
         }
       }
@@ -418,14 +415,10 @@ __global__ __launch_bounds__(256) void t5_attn_bwd_mfma(AttnMP p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int q = qt * 16 + g * 4 + r;
-          float pdv = 0.f, dsv = 0.f;
-          if (key < Lk && q < Lq && !(p.causal && key > q)) {
-            const float x = st[r] * sscale + bcur[u][r];
-            const float pr = __expf(x - lses[q]);
-            const float mlt = drop_mult32(dc, (uint32_t)q * (uint32_t)Lk + key);
-            pdv = pr * mlt;
-            dsv = pr * (dpt[r] * mlt - delta[q]);
-          }
+          const bool ok = key < Lk && q < Lq && !(p.causal && key > q);
+          const float pr = ok ? __expf(st[r] * sscale + bcur[u][r] - lses[q]) : 0.f;
+          const float mlt = drop_mult32_nb(dc, (uint32_t)q * (uint32_t)Lk + key);
+          const float pdv = pr * mlt, dsv = pr * (dpt[r] * mlt - delta[q]);
           pd2[u][r] = pdv; ds2[u][r] = dsv;
         }
       }
@@ -600,12 +593,13 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(FlashP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int kl = t * 16 + g * 4 + r, key = k0 + kl;
-        float x = -INFINITY;
-        if (key < Lk) {
-          x = s[t][r] * sscale;
-          if constexpr (BIAS == 1) x += brow[key];
-          if constexpr (BIAS == 2) { x += tab[coff - kcode[kl]]; if (kreg[kl] != qreg) x += -200.f; }
-        }
+        // branch-free: every LDS read below is in range for any kl (kcode / kreg are filled for all 64 slots, code 0 for keys past
+        // the end), the result of an out-of-range key is discarded by the select.  (Sixteen per-element branches split this loop
+        // into a hundred basic blocks.)
+        float x = s[t][r] * sscale;
+        if constexpr (BIAS == 1) x += brow[key < Lk ? key : Lk - 1];
+        if constexpr (BIAS == 2) x += tab[coff - kcode[kl]] + (kreg[kl] != qreg ? -200.f : 0.f);
+        x = key < Lk ? x : -INFINITY;
         s[t][r] = x;
         mb = fmaxf(mb, x);
       }
@@ -622,7 +616,8 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(FlashP p) {
       for (int r = 0; r < 4; ++r) {
         const float e = __expf(s[t][r] - mn);
         sum += e;
-        s[t][r] = e * drop_mult32(dc, dbase + t * 16 + g * 4 + r);
+        if constexpr (BIAS == 2) s[t][r] = e;  // (window attention has no probability dropout: HF/swinv2 attention_probs_dropout_prob = 0)
+        else s[t][r] = e * drop_mult32(dc, dbase + t * 16 + g * 4 + r);
       }
     l = l * corr + sum;
     m = mn;
@@ -895,12 +890,8 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_swin_kernel(FlashP p, int
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int kl = t * 16 + g * 4 + r, key = k0 + kl;
-            float dsv = 0.f;
-            if (key < Lk && q < Lq) {
-              float x = st[r] * sscale + tab[coff - kcode[kl]];
-              if (kreg[kl] != qreg) x += -200.f;
-              dsv = __expf(x - lq) * (dpt[r] - delta);
-            }
+            const float x = st[r] * sscale + tab[coff - kcode[kl]] + (kreg[kl] != qreg ? -200.f : 0.f);  // (branch-free, as the forward)
+            const float dsv = (key < Lk && q < Lq) ? __expf(x - lq) * (dpt[r] - delta) : 0.f;
             ds2[u][r] = dsv;
             dsacc[kb][t][r] += dsv;
           }
@@ -1040,10 +1031,14 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(FlashP p) {
         for (int r = 0; r < 4; ++r) {
           const int ql = qt * 16 + g * 4 + r, qq = i0 + ql;
           float pdv = 0.f, dsv = 0.f;
-          if (key < Lk && qq < Lq) {
+          if constexpr (BIAS == 2) {  // branch-free (no dropout in window attention); padded queries carry lse = +inf => P = 0
+            const float x = st[r] * sscale + tab[qcode[ql] + koff] + (qreg[ql] != kreg_ ? -200.f : 0.f);
+            const float pr = (key < Lk && qq < Lq) ? __expf(x - lses[ql]) : 0.f;
+            pdv = pr;
+            dsv = pr * (dpt[r] - delta[ql]);
+          } else if (key < Lk && qq < Lq) {
             float x = st[r] * sscale;
             if constexpr (BIAS == 1) x += biasp[(long)qq * Lk + key];
-            if constexpr (BIAS == 2) { x += tab[qcode[ql] + koff]; if (qreg[ql] != kreg_) x += -200.f; }
             const float pr = __expf(x - lses[ql]);
             const float mlt = drop_mult32(dc, (uint32_t)qq * (uint32_t)Lk + key);
             pdv = pr * mlt;

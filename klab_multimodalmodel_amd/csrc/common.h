@@ -82,6 +82,11 @@ __device__ __forceinline__ float drop_mult32(const DropCtx& d, uint32_t off) {
   if (!d.on) return 1.f;
   return mix32(off * 0x9E3779B1u + d.key) < d.thresh ? 0.f : d.scale;
 }
+// the same value without the branch on d.on (thresh = 0 and scale = 1 when dropout is off: nothing is ever below 0): for unrolled
+// per-element code, where sixteen copies of that branch cut the loop body into as many basic blocks
+__device__ __forceinline__ float drop_mult32_nb(const DropCtx& d, uint32_t off) {
+  return mix32(off * 0x9E3779B1u + d.key) < d.thresh ? 0.f : d.scale;
+}
 
 // ---- wave / block reductions ---------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
