@@ -185,7 +185,10 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
 // Fused row + weight-gradient variant for d <= 256*SLOTS: the row's x / dy_eff stay in registers between the two passes,
 // each lane keeps the dw partial of its own columns over the block's rows, the 4 waves fold through LDS and a block
 // issues ONE f32 atomic per column (<= KLAB_RMS_BLOCKS-way contention; the un-reduced per-wave atomics were 10x slower).
-template <typename TY, int SLOTS>
+// IDX32: rows * d < 2^32, so an element's dropout index fits 32 bits and the one-round hash of drop_mult (high word zero) is
+// evaluated without its two branches (drop_mult32_nb gives the identical multiplier): sixteen copies of them per row otherwise cut
+// the unrolled body into ~56 basic blocks
+template <typename TY, int SLOTS, bool IDX32 = false>
 __global__ __launch_bounds__(1024) void rmsnorm_bwd_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              const float* __restrict__ w, const float* __restrict__ rstd,
                                                              const float* __restrict__ dres, float* __restrict__ dx,
@@ -228,7 +231,8 @@ __global__ __launch_bounds__(1024) void rmsnorm_bwd_dw_kernel(const float* __res
       if (c < d) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          e[s][i] *= drop_mult(dcy, (uint64_t)yrow * d + c + i);
+          if constexpr (IDX32) e[s][i] *= drop_mult32_nb(dcy, (uint32_t)yrow * (uint32_t)d + c + i);
+          else e[s][i] *= drop_mult(dcy, (uint64_t)yrow * d + c + i);
           dot += e[s][i] * g[s][i] * v[s][i];
           acc[s][i] += e[s][i] * v[s][i] * r;
         }
@@ -246,7 +250,10 @@ __global__ __launch_bounds__(1024) void rmsnorm_bwd_dw_kernel(const float* __res
         if (dx) store4<float>(dx + row * d + c, o[0], o[1], o[2], o[3]);
         if (dxt) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) o[i] *= drop_mult(dcp, (uint64_t)row * d + c + i);
+          for (int i = 0; i < 4; ++i) {
+            if constexpr (IDX32) o[i] *= drop_mult32_nb(dcp, (uint32_t)row * (uint32_t)d + c + i);
+            else o[i] *= drop_mult(dcp, (uint64_t)row * d + c + i);
+          }
           store4<TY>(dxt + row * d + c, o[0], o[1], o[2], o[3]);
         }
       }
@@ -592,9 +599,17 @@ static int rms_fused_launch(const float* dy, const float* x, const float* w, con
                             int dxt_dtype, float* dw, int partial, int rows, int d, int grp, int grp_stride, int off, float p_y,
                             uint32_t tag_y, float p_prev, uint32_t tag_prev, const uint32_t* seed_dev, hipStream_t s) {
   const int gf = rms_part_rows(rows);
+  // (the remapped output row space is at most grp_stride / grp times larger than rows; 2^31 leaves that room)
+  const bool idx32 = (long)rows * d < (1L << 31) && (grp <= 0 || (long)grp_stride * ((rows + grp - 1) / grp + 1) * d < (1L << 31));
 #define RB_LAUNCH(TY, SL)                                                                                                      \
-  hipLaunchKernelGGL((rmsnorm_bwd_dw_kernel<TY, SL>), dim3(gf), dim3(1024), 0, s, dy, x, w, rstd, dres, dx, (TY*)dxt, dw, rows, d, grp, \
-                     grp_stride, off, p_y, tag_y, p_prev, tag_prev, seed_dev, partial)
+  do {                                                                                                                         \
+    if (idx32)                                                                                                                 \
+      hipLaunchKernelGGL((rmsnorm_bwd_dw_kernel<TY, SL, true>), dim3(gf), dim3(1024), 0, s, dy, x, w, rstd, dres, dx, (TY*)dxt, dw, rows, d, grp, \
+                         grp_stride, off, p_y, tag_y, p_prev, tag_prev, seed_dev, partial);                                    \
+    else                                                                                                                       \
+      hipLaunchKernelGGL((rmsnorm_bwd_dw_kernel<TY, SL, false>), dim3(gf), dim3(1024), 0, s, dy, x, w, rstd, dres, dx, (TY*)dxt, dw, rows, d, grp, \
+                         grp_stride, off, p_y, tag_y, p_prev, tag_prev, seed_dev, partial);                                    \
+  } while (0)
   if (dxt_dtype == KLAB_BF16) { if (d <= 256) RB_LAUNCH(bf16_t, 1); else if (d <= 512) RB_LAUNCH(bf16_t, 2); else RB_LAUNCH(bf16_t, 4); }
   else { if (d <= 256) RB_LAUNCH(float, 1); else if (d <= 512) RB_LAUNCH(float, 2); else RB_LAUNCH(float, 4); }
 #undef RB_LAUNCH
