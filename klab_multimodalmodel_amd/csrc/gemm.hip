@@ -266,7 +266,9 @@ __device__ __forceinline__ void staged_epilogue_v(const GemmP& p, f32x4 (&acc)[M
           }
           if constexpr (FLAGS & EF_AUXNZ_CO) x *= p.aux_scale;  // the zero mask itself is applied at copy-out
           if constexpr (FLAGS & EF_DGELU) x *= gelu_erf_grad(to_f32(reinterpret_cast<const T*>(p.aux)[(long)mc * p.ldaux + nc]));
-          if constexpr (FLAGS & EF_DROP) x *= drop_mult(dc, (uint64_t)mc * (uint64_t)p.N + (uint64_t)nc);
+          // (the dedicated variants are only selected for M * N < 2^32 -- fill_gemmp -- where the one-round, branch-free hash equals
+          // drop_mult's; 64 copies of its two branches otherwise chop the unrolled epilogue into basic blocks)
+          if constexpr (FLAGS & EF_DROP) x *= drop_mult32_nb(dc, (uint32_t)mc * (uint32_t)p.N + (uint32_t)nc);
           if constexpr (FLAGS & EF_RES) {
             x += p.r_f32 ? reinterpret_cast<const float*>(p.residual)[(long)mc * p.ldr + nc]
                          : to_f32(reinterpret_cast<const T*>(p.residual)[(long)mc * p.ldr + nc]);
@@ -1398,6 +1400,7 @@ static void fill_gemmp(const klab_gemm_args* a, GemmP& p) {
           !(a->ldr & 3) && !((uintptr_t)a->residual & 15))
         f = (f & ~EF_RES) | EF_RES_CO;
     }
+    if ((f & EF_DROP) && (long)a->M * a->N >= (1L << 32)) f = EF_GENERIC;  // dropout indices beyond 32 bits: the general body hashes 64-bit indices
     p.epi = f;  // combinations without a dedicated variant fall into the generic body (switch default)
   }
   {
