@@ -241,11 +241,9 @@ __global__ __launch_bounds__(64) void swin_attn_fwd_mfma32(SwinAttnP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = t * 16 + g * 4 + r;
-        float x = -INFINITY;
-        if (key < n) {
-          x = st[t][r] * scale + bcur[t][r];
-          if (reg[key] != rq) x += -200.f;  // -100 twice (HF/swinv2:433-436)
-        }
+        // branch-free (reg[] has all 64 slots, the bias fetch is clamped): -100 twice for another shift region (HF/swinv2:433-436)
+        float x = st[t][r] * scale + bcur[t][r] + (reg[key] != rq ? -200.f : 0.f);
+        x = key < n ? x : -INFINITY;
         st[t][r] = x;
         m = fmaxf(m, x);
       }
@@ -453,11 +451,9 @@ __global__ __launch_bounds__(64) void swin_qkv_attn_fused(SwinQkvP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = t * 16 + g * 4 + r;
-        float x = -INFINITY;
-        if (key < n) {
-          x = st[t][r] * scale + bcur[t][r];
-          if (reg[key] != rq) x += -200.f;  // -100 twice (HF/swinv2:433-436)
-        }
+        // branch-free (reg[] has all 64 slots, the bias fetch is clamped): -100 twice for another shift region (HF/swinv2:433-436)
+        float x = st[t][r] * scale + bcur[t][r] + (reg[key] != rq ? -200.f : 0.f);
+        x = key < n ? x : -INFINITY;
         st[t][r] = x;
         m = fmaxf(m, x);
       }
