@@ -293,6 +293,43 @@ __device__ __forceinline__ void copy_out_tile(const GemmP& p, const char* smem, 
   const bool vec_ok = ((p.ldc * esz) & 15) == 0 && (p.N & ((1 << sh) - 1)) == 0;
   char* Cb = reinterpret_cast<char*>(p.C);
   const int nch = BM << cpr_sh;
+  // Interior tiles (the common case) with whole 16-byte rows: every chunk of the thread is read from LDS -- and its residual /
+  // mask operand requested from memory -- BEFORE the first store.  The general loop below does read, (load,) store per chunk; on
+  // this ISA a store counts in vmcnt like a load, so each chunk's operand wait also drained the stores issued before it: 8-16
+  // memory round trips in a row at the end of every tile.
+  if (bm0 + BM <= p.M && bn0 + BN <= p.N && vec_ok && !p.accumulate && !(p.ablate & 64)) {
+    auto fast = [&](auto esz_c) {
+      constexpr int ESZ = decltype(esz_c)::value, EPC = 16 / ESZ, CPR = BN / EPC, PER = BM * CPR / 256;
+      static_assert(BM * CPR % 256 == 0, "whole chunks per thread");
+      f32x4 val[PER], opnd[PER];
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int ch = tid + i * 256, row = ch / CPR, cc = ch % CPR;
+        val[i] = *reinterpret_cast<const f32x4*>(smem + row * ((BN + 16 / ESZ) * ESZ) + cc * 16);
+        const long m = bm0 + row, n = bn0 + cc * EPC;
+        if constexpr ((CO & EF_RES_CO) != 0) opnd[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.residual) + m * p.ldr + n);
+        if constexpr ((CO & EF_AUXNZ_CO) != 0) opnd[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const bf16_t*>(p.aux) + m * p.ldaux + n);
+      }
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int ch = tid + i * 256, row = ch / CPR, cc = ch % CPR;
+        const long m = bm0 + row, n = bn0 + cc * EPC;
+        f32x4 v = val[i];
+        if constexpr ((CO & EF_RES_CO) != 0) { v[0] += opnd[i][0]; v[1] += opnd[i][1]; v[2] += opnd[i][2]; v[3] += opnd[i][3]; }
+        if constexpr ((CO & EF_AUXNZ_CO) != 0) {
+          bf16x8 nv = __builtin_bit_cast(bf16x8, v);
+          const bf16x8 a = __builtin_bit_cast(bf16x8, opnd[i]);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) nv[u] = ((float)a[u] != 0.f) ? nv[u] : (bf16_t)0.f;
+          v = __builtin_bit_cast(f32x4, nv);
+        }
+        *reinterpret_cast<f32x4*>(Cb + (m * p.ldc + n) * ESZ) = v;
+      }
+    };
+    if (f32out) fast(std::integral_constant<int, 4>{});
+    else fast(std::integral_constant<int, 2>{});
+    return;
+  }
   for (int ch = tid; ch < nch; ch += 256) {
     const int row = ch >> cpr_sh, cc = ch & ((1 << cpr_sh) - 1);
     const int m = bm0 + row, n = bn0 + (cc << sh);

@@ -33,7 +33,7 @@ template <> __device__ __forceinline__ f32x4 load4<bf16_t>(const bf16_t* p) {
 // ------------------------------------------------------------------------------------------
 // RMS-norm forward: y = drop(x * rsqrt(mean(x^2)+eps) * w)
 // ------------------------------------------------------------------------------------------
-template <typename TY>
+template <typename TY, bool DROP = true>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           TY* __restrict__ y, float* __restrict__ y32, float* __restrict__ rstd, int rows,
                                                           int d, float eps, int grp, int grp_stride, int off, float p,
@@ -57,7 +57,10 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
       f32x4 g = *reinterpret_cast<const f32x4*>(w + c);
       float o[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = g[i] * (v[i] * r) * drop_mult(dc, (uint64_t)orow * d + c + i);
+      for (int i = 0; i < 4; ++i) {
+        o[i] = g[i] * (v[i] * r);
+        if constexpr (DROP) o[i] *= drop_mult(dc, (uint64_t)orow * d + c + i);  // (most norms have no output dropout: no hash, no branches)
+      }
       if (y) store4<TY>(y + orow * d + c, o[0], o[1], o[2], o[3]);
       if (y32) store4<float>(y32 + orow * d + c, o[0], o[1], o[2], o[3]);
     }
@@ -346,8 +349,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const TI* __restrict
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] += q[i];
       }
+      if (dc.on) {  // (one uniform test per chunk instead of one per element inside drop_mult)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] *= drop_mult(dc, (uint64_t)orow * C + c + i);
+        for (int i = 0; i < 4; ++i) o[i] *= drop_mult(dc, (uint64_t)orow * C + c + i);
+      }
       if (out) store4<float>(out + orow * C + c, o[0], o[1], o[2], o[3]);
       if (outt) store4<TO>(outt + orow * C + c, o[0], o[1], o[2], o[3]);
       if constexpr (Q8) {
@@ -564,12 +569,13 @@ extern "C" int klab_rmsnorm_fwd(const float* x, const float* w, void* y, int y_d
   if (!x || !w || rows < 0 || d <= 0 || (d & 3)) return KLAB_ERR_BADARG;
   if (rows == 0) return KLAB_OK;
   hipStream_t s = (hipStream_t)stream;
-  if (y_dtype == KLAB_BF16)
-    hipLaunchKernelGGL(rmsnorm_fwd_kernel<bf16_t>, dim3(norm_grid(rows)), dim3(256), 0, s, x, w, (bf16_t*)y, y_f32, rstd, rows, d,
-                       eps, grp, grp_stride, off, drop_p, seed_dev, tag);
-  else
-    hipLaunchKernelGGL(rmsnorm_fwd_kernel<float>, dim3(norm_grid(rows)), dim3(256), 0, s, x, w, (float*)y, y_f32, rstd, rows, d,
-                       eps, grp, grp_stride, off, drop_p, seed_dev, tag);
+  const bool drop = drop_p > 0.f && seed_dev;
+#define RF(TY, DR)                                                                                                              \
+  hipLaunchKernelGGL((rmsnorm_fwd_kernel<TY, DR>), dim3(norm_grid(rows)), dim3(256), 0, s, x, w, (TY*)y, y_f32, rstd, rows, d, eps, grp, \
+                     grp_stride, off, drop_p, seed_dev, tag)
+  if (y_dtype == KLAB_BF16) { if (drop) RF(bf16_t, true); else RF(bf16_t, false); }
+  else { if (drop) RF(float, true); else RF(float, false); }
+#undef RF
   KLAB_LAUNCH_CHECK();
   return KLAB_OK;
 }
