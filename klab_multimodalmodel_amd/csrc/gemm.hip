@@ -214,7 +214,10 @@ enum : int { EF_BIAS = 1, EF_RELU = 2, EF_GELU = 4, EF_AUXNZ = 8, EF_DGELU = 16,
              // the same two features applied while the staged tile is streamed out (16 B per lane, row-contiguous: coalesced
              // reads of the mask / residual) instead of in the MFMA layout (2- and 4-byte reads of 16 rows per instruction:
              // the relu-mask dgrad ran at 38 us against 16 us for the plain GEMM); chosen on the host when dtypes/alignment allow
-             EF_AUXNZ_CO = 256, EF_RES_CO = 512 };
+             EF_AUXNZ_CO = 256, EF_RES_CO = 512,
+             // gelu'(z) applied while the staged bf16 tile is streamed out: z is read as whole 16-byte row pieces (in the MFMA layout each
+             // lane fetched 64 separate 2-byte values from 16 different rows)
+             EF_DGELU_CO = 1024 };
 
 // FLAGS is a compile-time feature set: each variant contains only the code of its features, fully unrolled over the
 // lane's 16-64 accumulator elements (~0.3-2 K instructions).  One big run-time-flagged body (every feature x every
@@ -309,7 +312,7 @@ __device__ __forceinline__ void copy_out_tile(const GemmP& p, const char* smem, 
         const long m = bm0 + row, n = bn0 + cc * EPC;
         if constexpr (CO == 0 && ESZ == 4) { if (p.accumulate) opnd[i] = *reinterpret_cast<const f32x4*>(Cb + (m * p.ldc + n) * ESZ); }  // C += tile
         if constexpr ((CO & EF_RES_CO) != 0) opnd[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.residual) + m * p.ldr + n);
-        if constexpr ((CO & EF_AUXNZ_CO) != 0) opnd[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const bf16_t*>(p.aux) + m * p.ldaux + n);
+        if constexpr ((CO & (EF_AUXNZ_CO | EF_DGELU_CO)) != 0) opnd[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const bf16_t*>(p.aux) + m * p.ldaux + n);
       }
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
@@ -323,6 +326,13 @@ __device__ __forceinline__ void copy_out_tile(const GemmP& p, const char* smem, 
           const bf16x8 a = __builtin_bit_cast(bf16x8, opnd[i]);
 #pragma unroll
           for (int u = 0; u < 8; ++u) nv[u] = ((float)a[u] != 0.f) ? nv[u] : (bf16_t)0.f;
+          v = __builtin_bit_cast(f32x4, nv);
+        }
+        if constexpr ((CO & EF_DGELU_CO) != 0) {
+          bf16x8 nv = __builtin_bit_cast(bf16x8, v);
+          const bf16x8 a = __builtin_bit_cast(bf16x8, opnd[i]);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) nv[u] = (bf16_t)((float)nv[u] * gelu_erf_grad((float)a[u]));
           v = __builtin_bit_cast(f32x4, nv);
         }
         *reinterpret_cast<f32x4*>(Cb + (m * p.ldc + n) * ESZ) = v;
@@ -343,6 +353,14 @@ __device__ __forceinline__ void copy_out_tile(const GemmP& p, const char* smem, 
       const bf16x8 a = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.aux) + (long)m * p.ldaux + n);
 #pragma unroll
       for (int u = 0; u < 8; ++u) nv[u] = ((float)a[u] != 0.f) ? nv[u] : (bf16_t)0.f;
+      *reinterpret_cast<bf16x8*>(dst) = nv;
+      continue;
+    }
+    if constexpr (CO & EF_DGELU_CO) {  // bf16 tile, bf16 pre-activation, vector path guaranteed by the host
+      bf16x8 nv = *reinterpret_cast<const bf16x8*>(src);
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.aux) + (long)m * p.ldaux + n);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) nv[u] = (bf16_t)((float)nv[u] * gelu_erf_grad((float)a[u]));
       *reinterpret_cast<bf16x8*>(dst) = nv;
       continue;
     }
@@ -406,6 +424,7 @@ __device__ __forceinline__ void staged_epilogue(const GemmP& p, f32x4 (&acc)[MI]
     case EF_AUXNZ: KLAB_EPI(EF_AUXNZ); break;
     case EF_DGELU: KLAB_EPI(EF_DGELU); break;
     case EF_AUXNZ_CO: KLAB_EPI(EF_AUXNZ_CO); break;
+    case EF_DGELU_CO: KLAB_EPI(0); break;
     case EF_RES_CO: KLAB_EPI(0); break;
     case EF_DROP | EF_RES_CO: KLAB_EPI(EF_DROP); break;
     default: KLAB_EPI(EF_GENERIC); break;
@@ -415,6 +434,7 @@ __device__ __forceinline__ void staged_epilogue(const GemmP& p, f32x4 (&acc)[MI]
   if (p.ablate & 8) return;
   if constexpr (sizeof(T) == 2) {
     if (p.epi == EF_AUXNZ_CO) { copy_out_tile<T, BM, BN, EF_AUXNZ_CO>(p, smem, bm0, bn0, tid); return; }
+    if (p.epi == EF_DGELU_CO) { copy_out_tile<T, BM, BN, EF_DGELU_CO>(p, smem, bm0, bn0, tid); return; }
   }
   if (p.epi == EF_RES_CO || p.epi == (EF_DROP | EF_RES_CO)) { copy_out_tile<T, BM, BN, EF_RES_CO>(p, smem, bm0, bn0, tid); return; }
   copy_out_tile<T, BM, BN>(p, smem, bm0, bn0, tid);
@@ -1437,6 +1457,8 @@ static void fill_gemmp(const klab_gemm_args* a, GemmP& p) {
     // aligned 16-byte vector and nothing is accumulated into C
     if (!a->accumulate && a->dtype == KLAB_BF16) {
       if (f == EF_AUXNZ && a->c_dtype == KLAB_BF16 && !(a->N & 7) && !(a->ldc & 7) && !(a->ldaux & 7) && !((uintptr_t)a->aux & 15)) f = EF_AUXNZ_CO;
+      static const bool dgelu_co = [] { const char* e = getenv("KLAB_GEMM_DGELU_CO"); return !e || atoi(e) != 0; }();
+      if (dgelu_co && f == EF_DGELU && a->c_dtype == KLAB_BF16 && !(a->N & 7) && !(a->ldc & 7) && !(a->ldaux & 7) && !((uintptr_t)a->aux & 15)) f = EF_DGELU_CO;
       if ((f == EF_RES || f == (EF_DROP | EF_RES)) && a->c_dtype == KLAB_F32 && a->r_dtype == KLAB_F32 && !(a->N & 3) && !(a->ldc & 3) &&
           !(a->ldr & 3) && !((uintptr_t)a->residual & 15))
         f = (f & ~EF_RES) | EF_RES_CO;

@@ -511,7 +511,7 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_fused_kernel(const float* 
       if (c < C) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          e[s][i] *= drop_mult(dc, (uint64_t)orow * C + c + i);
+          if (dc.on) e[s][i] *= drop_mult(dc, (uint64_t)orow * C + c + i);  // (uniform; Swin has no dropout here)
           xh[s][i] = (xh[s][i] - mu) * r;
           s1 += g[s][i] * e[s][i];
           s2 += g[s][i] * e[s][i] * xh[s][i];
