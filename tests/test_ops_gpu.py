@@ -864,3 +864,18 @@ def test_error_paths_of_the_entry_points_added_in_round_two(ops):
         L.check(lib.klab_jpeg_decode_device(*args, 16, None), "jpeg")
     assert lib.klab_jpeg_decode_ws_bytes(C.cast(items, C.c_void_p), 1) >= 64
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("M,N,K,pad", [(384, 256, 128, 0), (300, 264, 96, 0), (256, 128, 64, 4), (1000, 512, 256, 0)])
+def test_gemm_dgelu_aux_epilogue(ops, M, N, K, pad):
+    """dZ = (dY @ W) * gelu'(Z) (the trainable Swin MLP backward, HF/swinv2:539-563 under autograd): the copy-out form (whole
+    16-byte pieces of Z) and, with a row pitch of Z that is not a multiple of 8 elements, the in-register form"""
+    dt = torch.bfloat16
+    dy, w = rnd(M, K, seed=1).to(dt), rnd(K, N, seed=2, scale=0.2).to(dt)
+    zfull = (2 * rnd(M, N + pad, seed=3)).to(dt)
+    z = zfull[:, :N]
+    ref = (dy.float() @ w.float()) * (0.5 * (1 + torch.erf(z.float() / 2 ** 0.5)) + z.float() * torch.exp(-0.5 * z.float() ** 2) / (2 * torch.pi) ** 0.5)
+    zd = dev(zfull)[:, :N]
+    c = torch.empty(M, N, device="cuda", dtype=dt)
+    ops.gemm(dev(dy), dev(w), c, M=M, N=N, K=K, a_kmajor=True, b_kmajor=False, aux=zd, aux_mode=ops.L.AUX_DGELU)
+    assert rel_l2(c.float().cpu(), ref) < 8e-3
