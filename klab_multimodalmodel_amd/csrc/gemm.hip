@@ -286,7 +286,7 @@ __device__ __forceinline__ void staged_epilogue_v(const GemmP& p, f32x4 (&acc)[M
   }
 }
 
-template <typename T, int BM, int BN, int CO = 0>
+template <typename T, int BM, int BN, int CO = 0, int NT = 256>
 __device__ __forceinline__ void copy_out_tile(const GemmP& p, const char* smem, int bm0, int bn0, int tid) {
   const bool f32out = p.c_f32 || sizeof(T) == 4;
   const int pitchB = f32out ? (BN + 4) * 4 : (BN + 8) * 2;
@@ -302,12 +302,12 @@ __device__ __forceinline__ void copy_out_tile(const GemmP& p, const char* smem, 
   // memory round trips in a row at the end of every tile.
   if (bm0 + BM <= p.M && bn0 + BN <= p.N && vec_ok && (!p.accumulate || (f32out && CO == 0)) && !(p.ablate & 64)) {
     auto fast = [&](auto esz_c) {
-      constexpr int ESZ = decltype(esz_c)::value, EPC = 16 / ESZ, CPR = BN / EPC, PER = BM * CPR / 256;
-      static_assert(BM * CPR % 256 == 0, "whole chunks per thread");
+      constexpr int ESZ = decltype(esz_c)::value, EPC = 16 / ESZ, CPR = BN / EPC, PER = BM * CPR / NT;
+      static_assert(BM * CPR % NT == 0, "whole chunks per thread");
       f32x4 val[PER], opnd[PER];
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
-        const int ch = tid + i * 256, row = ch / CPR, cc = ch % CPR;
+        const int ch = tid + i * NT, row = ch / CPR, cc = ch % CPR;
         val[i] = *reinterpret_cast<const f32x4*>(smem + row * ((BN + 16 / ESZ) * ESZ) + cc * 16);
         const long m = bm0 + row, n = bn0 + cc * EPC;
         if constexpr (CO == 0 && ESZ == 4) { if (p.accumulate) opnd[i] = *reinterpret_cast<const f32x4*>(Cb + (m * p.ldc + n) * ESZ); }  // C += tile
@@ -316,7 +316,7 @@ __device__ __forceinline__ void copy_out_tile(const GemmP& p, const char* smem, 
       }
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
-        const int ch = tid + i * 256, row = ch / CPR, cc = ch % CPR;
+        const int ch = tid + i * NT, row = ch / CPR, cc = ch % CPR;
         const long m = bm0 + row, n = bn0 + cc * EPC;
         f32x4 v = val[i];
         if constexpr (CO == 0 && ESZ == 4) { if (p.accumulate) { v[0] += opnd[i][0]; v[1] += opnd[i][1]; v[2] += opnd[i][2]; v[3] += opnd[i][3]; } }
@@ -342,7 +342,7 @@ __device__ __forceinline__ void copy_out_tile(const GemmP& p, const char* smem, 
     else fast(std::integral_constant<int, 2>{});
     return;
   }
-  for (int ch = tid; ch < nch; ch += 256) {
+  for (int ch = tid; ch < nch; ch += NT) {
     const int row = ch >> cpr_sh, cc = ch & ((1 << cpr_sh) - 1);
     const int m = bm0 + row, n = bn0 + (cc << sh);
     if (m >= p.M || n >= p.N) continue;
@@ -409,7 +409,7 @@ __device__ __forceinline__ void copy_out_tile(const GemmP& p, const char* smem, 
   }
 }
 
-template <typename T, int BM, int BN, int MI, int NI>
+template <typename T, int BM, int BN, int MI, int NI, int NT = 256>
 __device__ __forceinline__ void staged_epilogue(const GemmP& p, f32x4 (&acc)[MI][NI], float alpha, char* smem, int bm0, int bn0, int wm,
                                                 int wn, int tid, int lane) {
 #define KLAB_EPI(F) staged_epilogue_v<T, BM, BN, MI, NI, F>(p, acc, alpha, smem, bm0, bn0, wm, wn, tid, lane)
@@ -433,11 +433,11 @@ __device__ __forceinline__ void staged_epilogue(const GemmP& p, f32x4 (&acc)[MI]
   __syncthreads();
   if (p.ablate & 8) return;
   if constexpr (sizeof(T) == 2) {
-    if (p.epi == EF_AUXNZ_CO) { copy_out_tile<T, BM, BN, EF_AUXNZ_CO>(p, smem, bm0, bn0, tid); return; }
-    if (p.epi == EF_DGELU_CO) { copy_out_tile<T, BM, BN, EF_DGELU_CO>(p, smem, bm0, bn0, tid); return; }
+    if (p.epi == EF_AUXNZ_CO) { copy_out_tile<T, BM, BN, EF_AUXNZ_CO, NT>(p, smem, bm0, bn0, tid); return; }
+    if (p.epi == EF_DGELU_CO) { copy_out_tile<T, BM, BN, EF_DGELU_CO, NT>(p, smem, bm0, bn0, tid); return; }
   }
-  if (p.epi == EF_RES_CO || p.epi == (EF_DROP | EF_RES_CO)) { copy_out_tile<T, BM, BN, EF_RES_CO>(p, smem, bm0, bn0, tid); return; }
-  copy_out_tile<T, BM, BN>(p, smem, bm0, bn0, tid);
+  if (p.epi == EF_RES_CO || p.epi == (EF_DROP | EF_RES_CO)) { copy_out_tile<T, BM, BN, EF_RES_CO, NT>(p, smem, bm0, bn0, tid); return; }
+  copy_out_tile<T, BM, BN, 0, NT>(p, smem, bm0, bn0, tid);
 }
 template <int BM, int BN> constexpr int epilogue_lds_bytes(bool f32out) { return f32out ? BM * (BN + 4) * 4 : BM * (BN + 8) * 2; }
 
@@ -490,11 +490,11 @@ template <int LPS> __device__ __forceinline__ void wait_groups(int g) {
   }
 }
 
-template <int ROWS, bool KMAJOR>
+template <int ROWS, bool KMAJOR, int NWAVES = 4, int NFRAG = ROWS / 32>
 struct GldsOperand {
-  static constexpr int L = ROWS / 64;              // LDS-DMA instructions per wave per stage
+  static constexpr int L = ROWS / (16 * NWAVES);   // LDS-DMA instructions per wave per stage
   static constexpr int BYTES = ROWS * 64;          // one stage of this operand
-  static constexpr int NF = ROWS / 32;             // 16-row fragments per wave (the wave owns ROWS/2 rows)
+  static constexpr int NF = NFRAG;                 // 16-row fragments per wave (2 x 2 waves: the wave owns ROWS/2 rows)
   static constexpr int RPF = KMAJOR ? 1 : 2;       // LDS read instructions per fragment
   const bf16_t* src[L];
   long kstep;                                      // elements to advance per k-tile
@@ -737,6 +737,179 @@ __device__ __forceinline__ void gemm_glds_body(const GemmP& p, const int bid = b
     staged_epilogue<T, BM, BN, MI, NI>(p, acc, alpha, smem, bm0, bn0, wm, wn, tid, lane);
   }
 }
+template <bool BKM>
+__device__ __forceinline__ void gemm_glds_w8_body(const GemmP& p, const int bid = blockIdx.x) {
+  typedef bf16_t T;
+  constexpr int BM = 256, BN = 128;
+  constexpr bool AK = true, ATOMIC = false;
+  constexpr int BK = 32, S = KLAB_GLDS_STAGES;
+  static_assert(S == 4, "the steady-state loop is unrolled over a 4-stage ring");
+  constexpr int WTM = BM / 4, WTN = BN / 2, MI = WTM / 16, NI = WTN / 16;  // 4 x 2 waves of 64 x 64
+  typedef GldsOperand<BM, AK, 8, MI> OA;
+  typedef GldsOperand<BN, BKM, 8, NI> OB;
+  constexpr int ABYTES = OA::BYTES, STAGE = OA::BYTES + OB::BYTES;
+  constexpr int LPS = OA::L + OB::L;                    // LDS-DMA instructions per wave per stage
+  constexpr int NRA = MI * OA::RPF, NRB = NI * OB::RPF;  // LDS read instructions per wave per k-tile
+  constexpr int NMMA = MI * NI, NOTH = NRA + NRB + LPS;
+  static_assert(2 * STAGE + 8192 <= 65536, "immediate LDS offsets: two stages per base register");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = (wave >> 1) * WTM, wn = (wave & 1) * WTN;  // wave 0..7
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  const int tile = bid % tiles, split = bid / tiles;
+  int bm0, bn0;
+  tile_of_block(p, BM, BN, tile, bm0, bn0);
+  const int nt_all = p.K / BK;
+  const int per = (nt_all + p.splits - 1) / p.splits;
+  const int kt0 = split * per, kt1 = (kt0 + per < nt_all) ? kt0 + per : nt_all;
+  const int nt = kt1 - kt0;
+  if (nt <= 0) return;
+
+  OA oa; OB ob;
+  oa.init(reinterpret_cast<const T*>(p.A), p.lda, bm0, p.M, wave, lane, wm);
+  ob.init(reinterpret_cast<const T*>(p.B), p.ldb, bn0, p.N, wave, lane, wn);
+  // k-tiles are visited in a per-workgroup rotated order: workgroups that share an A or B panel start together,
+  // and in lockstep they would all hit the same few L2 channels at once; rotating by the tile coordinates spreads
+  // each panel's readers over its whole K extent (only the fp32 summation order changes).
+  const int skew = ((bm0 / BM) * 5 + (bn0 / BN) * 3) % nt;
+  auto ktile = [&](int t) { int kk = t + skew; return kt0 + (kk >= nt ? kk - nt : kk); };
+  // ds_read immediates are 16 bits and the ring is 96 KB: stages 0-1 are addressed from sb0, stages 2-3 from sb1
+  const unsigned sb0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem, sb1 = sb0 + 2 * STAGE;
+#define KLAB_SB(SN) (((SN) >> 1) ? sb1 : sb0)
+#define KLAB_SO(SN) (((SN) & 1) * STAGE)
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 a0[MI], b0[NI], a1[MI], b1[NI];
+
+  // "other" operation o of a step: first the LDS reads of the next k-tile (early, so they have the rest of the step to
+  // land), then the LDS-DMA instructions.  SN = ring slot of the k-tile being read, SD = slot being refilled.
+#define KLAB_OTHER(O, SN, SD, NA, NB, DO_DMA, KT)                                                          \
+  if constexpr ((O) < NRA) oa.template read1<(O), KLAB_SO(SN)>(KLAB_SB(SN), NA);                           \
+  else if constexpr ((O) < NRA + NRB) ob.template read1<(O) - NRA, KLAB_SO(SN) + ABYTES>(KLAB_SB(SN), NB);  \
+  else if (DO_DMA) {                                                                                       \
+    constexpr int d = (O) - NRA - NRB;                                                                     \
+    if constexpr (d < OA::L) oa.issue1(d, KT, smem + (SD) * STAGE, wave);                                  \
+    else ob.issue1(d - OA::L, KT, smem + (SD) * STAGE + ABYTES, wave);                                     \
+  }
+  // MFMAs of the current fragments (CA, CB) with the other operations spread between them
+  auto mma_and = [&](auto sn_c, auto sd_c, const u32x4 (&ca)[MI], const u32x4 (&cb)[NI], u32x4 (&na)[MI], u32x4 (&nb)[NI],
+                     bool do_read, bool do_dma, int kt) {
+    constexpr int SN = decltype(sn_c)::value, SD = decltype(sd_c)::value;
+    auto other = [&](auto oc) {
+      constexpr int O = decltype(oc)::value;
+      if constexpr (O < NRA + NRB) { if (do_read) { KLAB_OTHER(O, SN, SD, na, nb, false, kt) } }
+      else { KLAB_OTHER(O, SN, SD, na, nb, do_dma, kt) }
+    };
+    auto unroll_other = [&](auto kc) {  // operations [k*NOTH/NMMA, (k+1)*NOTH/NMMA)
+      constexpr int k = decltype(kc)::value, lo = k * NOTH / NMMA, hi = (k + 1) * NOTH / NMMA;
+      if constexpr (hi - lo > 0) other(std::integral_constant<int, lo>{});
+      if constexpr (hi - lo > 1) other(std::integral_constant<int, lo + 1>{});
+      if constexpr (hi - lo > 2) other(std::integral_constant<int, lo + 2>{});
+      if constexpr (hi - lo > 3) other(std::integral_constant<int, lo + 3>{});
+      static_assert(hi - lo <= 4, "at most four slotted operations per MFMA gap");
+    };
+    auto one = [&](auto kc) {
+      constexpr int k = decltype(kc)::value, i = k / NI, j = k % NI;
+      if constexpr (ATOMIC) mfma_bf16_asm(acc[i][j], ca[i], cb[j]);
+      else mfma_bf16_asm(acc[i][j], cb[j], ca[i]);
+      unroll_other(kc);
+    };
+    [&]<int... Ks>(std::integer_sequence<int, Ks...>) { (one(std::integral_constant<int, Ks>{}), ...); }(std::make_integer_sequence<int, NMMA>{});
+  };
+
+  // prologue: k-tiles 0 .. S-1 fill the whole ring, the fragments of k-tile 0 come in
+#pragma unroll
+  for (int t = 0; t < S; ++t)
+    if (t < nt) {
+#pragma unroll
+      for (int d = 0; d < OA::L; ++d) oa.issue1(d, ktile(t), smem + t * STAGE, wave);
+#pragma unroll
+      for (int d = 0; d < OB::L; ++d) ob.issue1(d, ktile(t), smem + t * STAGE + ABYTES, wave);
+    }
+  wait_groups<LPS>((nt < S ? nt : S) - 1);  // k-tile 0 has landed
+  __builtin_amdgcn_s_barrier();
+  [&]<int... Rs>(std::integer_sequence<int, Rs...>) { (oa.template read1<Rs, 0>(sb0, a0), ...); }(std::make_integer_sequence<int, NRA>{});
+  [&]<int... Rs>(std::integer_sequence<int, Rs...>) { (ob.template read1<Rs, ABYTES>(sb0, b0), ...); }(std::make_integer_sequence<int, NRB>{});
+
+  int t = 0;
+  // one pipeline step on k-tile t held in (CA, CB) = ring slot SC: once every wave has its fragments of t in registers
+  // (lgkmcnt + barrier) slot SC is refilled with k-tile t+S, while k-tile t+1 (slot SC+1) is read into (NA, NB)
+#define KLAB_STEP(SC, CA, CB, NA, NB)                                                                                  \
+  {                                                                                                                   \
+    wait_lgkmcnt<0>();              /* fragments of k-tile t (issued one step ago) */                                  \
+    wait_vmcnt<(S - 2) * LPS>();    /* k-tile t+1 landed; S-2 younger groups stay in flight */                         \
+    __builtin_amdgcn_s_barrier();   /* t+1 visible to all waves; all waves hold k-tile t in registers: slot SC is free */ \
+    mma_and(std::integral_constant<int, ((SC) + 1) % S>{}, std::integral_constant<int, (SC)>{}, CA, CB, NA, NB, true, true, ktile(t + S)); \
+    ++t;                                                                                                              \
+  }
+  while (t + S + 3 < nt) {  // four straight-line steps: every step still has a k-tile to issue
+    KLAB_STEP(0, a0, b0, a1, b1)
+    KLAB_STEP(1, a1, b1, a0, b0)
+    KLAB_STEP(2, a0, b0, a1, b1)
+    KLAB_STEP(3, a1, b1, a0, b0)
+  }
+#undef KLAB_STEP
+  // Tail (t is a multiple of S; at most S+3 k-tiles): not pipelined.  Each step reads its own fragments into (a1, b1)
+  // and consumes them at once, so no asm-loaded register is live across a branch: hipcc copies such values at control
+  // flow merges, and a copy placed right behind the asm ds_read would pick the register up before the data lands.
+  auto mma_plain = [&](const u32x4 (&ca)[MI], const u32x4 (&cb)[NI]) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        if constexpr (ATOMIC) mfma_bf16_asm(acc[i][j], ca[i], cb[j]);
+        else mfma_bf16_asm(acc[i][j], cb[j], ca[i]);
+      }
+  };
+#define KLAB_TAIL(SC, FIRST)                                                                                              \
+  {                                                                                                                     \
+    if constexpr (!(FIRST)) {                                                                                           \
+      const int rem = nt - 1 - t;                                                                                       \
+      wait_groups<LPS>(rem < S - 1 ? rem : S - 1); /* k-tile t landed */                                                 \
+      __builtin_amdgcn_s_barrier();               /* ... for every wave */                                              \
+      [&]<int... Rs>(std::integer_sequence<int, Rs...>) { (oa.template read1<Rs, KLAB_SO(SC)>(KLAB_SB(SC), a1), ...); }(std::make_integer_sequence<int, NRA>{});          \
+      [&]<int... Rs>(std::integer_sequence<int, Rs...>) { (ob.template read1<Rs, KLAB_SO(SC) + ABYTES>(KLAB_SB(SC), b1), ...); }(std::make_integer_sequence<int, NRB>{}); \
+    }                                                                                                                   \
+    wait_lgkmcnt<0>();                                                                                                  \
+    if (t + S < nt) {                                                                                                   \
+      __builtin_amdgcn_s_barrier(); /* every wave holds k-tile t in registers: slot SC is free */                        \
+      _Pragma("unroll") for (int d = 0; d < OA::L; ++d) oa.issue1(d, ktile(t + S), smem + (SC) * STAGE, wave);           \
+      _Pragma("unroll") for (int d = 0; d < OB::L; ++d) ob.issue1(d, ktile(t + S), smem + (SC) * STAGE + ABYTES, wave);  \
+    }                                                                                                                   \
+    if constexpr (FIRST) mma_plain(a0, b0); /* prefetched by the prologue or by the last steady step */                  \
+    else mma_plain(a1, b1);                                                                                             \
+    ++t;                                                                                                                \
+  }
+  KLAB_TAIL(0, true)
+  while (t < nt) {
+    KLAB_TAIL(1, false)
+    if (t >= nt) break;
+    KLAB_TAIL(2, false)
+    if (t >= nt) break;
+    KLAB_TAIL(3, false)
+    if (t >= nt) break;
+    KLAB_TAIL(0, false)
+  }
+#undef KLAB_TAIL
+#undef KLAB_OTHER
+#undef KLAB_SB
+#undef KLAB_SO
+  // MFMA results are not interlocked against the v_accvgpr_read of the epilogue when the MFMA is inline asm
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  wait_vmcnt<0>();
+  float alpha = p.alpha;
+  if (p.alpha_dev) alpha *= p.alpha_dev[0];
+  __syncthreads();  // all LDS-DMA retired (vmcnt(0) above) and all fragment reads done: LDS is free for the epilogue
+  staged_epilogue<T, BM, BN, MI, NI, 512>(p, acc, alpha, smem, bm0, bn0, wm, wn, tid, lane);
+}
+template <bool BKM>
+__global__ __launch_bounds__(512) void gemm_glds_w8_kernel(GemmP p) { gemm_glds_w8_body<BKM>(p); }
+
 template <int BM, int BN, bool AK, bool BKM, bool ATOMIC>
 __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmP p) { gemm_glds_body<BM, BN, AK, BKM, ATOMIC>(p); }
 
@@ -968,6 +1141,28 @@ static int dispatch_tile(GemmP& p, bool atomic_ok, hipStream_t s) {
     if (force == 1) return dispatch_layout<T, 128, 128>(p, false, s);
     if (force == 2) return dispatch_layout<T, 128, 64>(p, false, s);
     if (force == 3) return dispatch_layout<T, 64, 64>(p, false, s);
+  }
+  if constexpr (sizeof(T) == 2) {
+    // 256 x 128 tiles on eight waves (4 x 2 of 64 x 64; 85 FLOP per operand byte instead of 64; one workgroup per CU).  Measured
+    // per shape (tools/gemm_bench.py, KLAB_GEMM_W8=2 forces it wherever it fits): it wins where 128 x 128 tiles need a second,
+    // poorly filled round of workgroups and the big tiles fit in ONE round (T5-large wo forward 75.7 -> 63.0 us, wi / qkv dgrad
+    // 64 -> 56 / 52 -> 47 us), ties or loses everywhere else (several rounds of one-per-CU workgroups expose every epilogue)
+    static const int w8 = [] { const char* e = getenv("KLAB_GEMM_W8"); return e ? atoi(e) : 1; }();
+    const bool w8_fits = p.a_kmajor && (p.K % 32) == 0 && p.K >= 128 && p.M >= 256 && p.N >= 128 && (p.b_kmajor || p.N >= 8);
+    // (inside the configs[1] step, K = 512, the same rule measured 0.7 % SLOWER -- 6.40 vs 6.35 ms -- hence K >= 1024; configs[4] +0.6 %)
+    if (w8_fits && (w8 == 2 || (w8 == 1 && p.K >= 1024 && tiles(128, 128) > 256 && tiles(256, 128) <= 256))) {
+      const int nt = p.K / 32;
+      size_t lds = (size_t)(nt < KLAB_GLDS_STAGES ? nt : KLAB_GLDS_STAGES) * (256 + 128) * 64;
+      const size_t epi = (size_t)epilogue_lds_bytes<256, 128>(p.c_f32);
+      if (epi > lds) lds = epi;
+      const void* kern = p.b_kmajor ? reinterpret_cast<const void*>(gemm_glds_w8_kernel<true>) : reinterpret_cast<const void*>(gemm_glds_w8_kernel<false>);
+      const int rc = ensure_dyn_lds(kern, lds);
+      if (rc) return rc;
+      if (p.b_kmajor) hipLaunchKernelGGL(gemm_glds_w8_kernel<true>, dim3((unsigned)tiles(256, 128)), dim3(512), lds, s, p);
+      else hipLaunchKernelGGL(gemm_glds_w8_kernel<false>, dim3((unsigned)tiles(256, 128)), dim3(512), lds, s, p);
+      KLAB_LAUNCH_CHECK();
+      return KLAB_OK;
+    }
   }
   if (tiles(128, 128) >= 240) return dispatch_layout<T, 128, 128>(p, false, s);
   if (tiles(128, 64) >= 240) return dispatch_layout<T, 128, 64>(p, false, s);

@@ -42,7 +42,7 @@ def main(path):
                 bad += 1
                 print(f"{name}: `{t}` reads {sorted(srcs & pending)} before the LDS data has landed")
     for line in open(path):
-        m = re.match(r"^(_ZN4klab\w*(gemm_glds_kernel|klab_lmhead_gemm|gemm_glds_fp8_kernel|gemm_glds_grouped_tn_kernel)\w*):", line)
+        m = re.match(r"^(_ZN4klab\w*(gemm_glds_kernel|klab_lmhead_gemm|gemm_glds_fp8_kernel|gemm_glds_grouped_tn_kernel|gemm_glds_w8_kernel)\w*):", line)
         if m:
             if name: check(name, body)
             name, body = m.group(1), []
