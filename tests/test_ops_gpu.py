@@ -879,3 +879,24 @@ def test_gemm_dgelu_aux_epilogue(ops, M, N, K, pad):
     c = torch.empty(M, N, device="cuda", dtype=dt)
     ops.gemm(dev(dy), dev(w), c, M=M, N=N, K=K, a_kmajor=True, b_kmajor=False, aux=zd, aux_mode=ops.L.AUX_DGELU)
     assert rel_l2(c.float().cpu(), ref) < 8e-3
+
+
+@pytest.mark.parametrize("M,N,K,bk", [(4896, 1024, 1024, True), (4900, 1000, 1056, True), (4896, 1024, 2048, False), (2048, 4096, 1024, True)])
+def test_gemm_eight_wave_256x128_tiles(ops, M, N, K, bk):
+    """the products the dispatcher gives to gemm_glds_w8_kernel (K >= 1024, more than 256 tiles of 128 x 128, at most 256 of
+    256 x 128): K-major and m-major B, ragged M / N edges, bf16 and f32 outputs, residual copy-out, bias + ReLU"""
+    dt = torch.bfloat16
+    A = rnd(M, K, seed=1).to(dt)
+    B = (rnd(N, K, seed=2, scale=0.05) if bk else rnd(K, N, seed=2, scale=0.05)).to(dt)
+    ref = A.float() @ (B.float().t() if bk else B.float())
+    for out_dt in (dt, torch.float32):
+        c = torch.empty(M, N, device="cuda", dtype=out_dt)
+        ops.gemm(dev(A), dev(B), c, M=M, N=N, K=K, b_kmajor=bk)
+        assert rel_l2(c.float().cpu(), ref) < (4e-3 if out_dt == dt else 1e-5)
+    res, bias = rnd(M, N, seed=3), rnd(N, seed=4)
+    c = torch.empty(M, N, device="cuda")
+    ops.gemm(dev(A), dev(B), c, M=M, N=N, K=K, b_kmajor=bk, residual=dev(res))
+    assert rel_l2(c.cpu(), ref + res) < 1e-5
+    c = torch.empty(M, N, device="cuda", dtype=dt)
+    ops.gemm(dev(A), dev(B), c, M=M, N=N, K=K, b_kmajor=bk, bias=dev(bias), act=ops.L.ACT_RELU)
+    assert rel_l2(c.float().cpu(), torch.relu(ref + bias)) < 4e-3
