@@ -700,15 +700,42 @@ __device__ __forceinline__ void gemm_glds_body(const GemmP& p, const int bid = b
     else mma_plain(a1, b1);                                                                                             \
     ++t;                                                                                                                \
   }
-  KLAB_TAIL(0, true)
-  while (t < nt) {
-    KLAB_TAIL(1, false)
-    if (t >= nt) break;
-    KLAB_TAIL(2, false)
-    if (t >= nt) break;
-    KLAB_TAIL(3, false)
-    if (t >= nt) break;
-    KLAB_TAIL(0, false)
+  // Exactly four k-tiles left, all of them already issued (K a multiple of 128 -- every T5 / Swin width): they drain through the
+  // same pipelined step as the steady state, without the DMA slot (the general tail below reads each tile's fragments and waits
+  // for them before its MFMAs: three exposed LDS round trips per tile of C).  The fragments of k-tile t are waited for BEFORE the
+  // branch, so that a register copy hipcc may place at the branch cannot pick up data that has not landed.
+  wait_lgkmcnt<0>();
+  if (nt - t == 4 && !(p.ablate & 128)) {
+    wait_vmcnt<2 * LPS>();
+    __builtin_amdgcn_s_barrier();
+    mma_and(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, a0, b0, a1, b1, true, false, 0);
+    wait_lgkmcnt<0>();
+    wait_vmcnt<LPS>();
+    __builtin_amdgcn_s_barrier();
+    mma_and(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, a1, b1, a0, b0, true, false, 0);
+    wait_lgkmcnt<0>();
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    mma_and(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{}, a0, b0, a1, b1, true, false, 0);
+    wait_lgkmcnt<0>();
+    mma_plain(a1, b1);
+    t += 4;
+    // the accumulators must not be touched before the last MFMA has retired (no interlock for inline-asm MFMAs), and hipcc places
+    // register copies at the join of the two branches: the nops go INSIDE each branch (found the hard way: the last k-tile of
+    // every product was lost)
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  } else {
+    KLAB_TAIL(0, true)
+    while (t < nt) {
+      KLAB_TAIL(1, false)
+      if (t >= nt) break;
+      KLAB_TAIL(2, false)
+      if (t >= nt) break;
+      KLAB_TAIL(3, false)
+      if (t >= nt) break;
+      KLAB_TAIL(0, false)
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   }
 #undef KLAB_TAIL
 #undef KLAB_OTHER

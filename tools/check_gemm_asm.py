@@ -51,7 +51,50 @@ def main(path):
             if "s_endpgm" in line:
                 check(name, body); name = None
     print(f"checked {nk} kernels, {bad} premature reads")
-    return 1 if bad else 0
+    bad2 = check_acc(path)
+    return 1 if (bad or bad2) else 0
+
+
+def check_acc(path):
+    """second rule: an inline-asm MFMA's destination is not interlocked -- no other instruction may read it until the pipe has
+    drained (the sources put `s_nop 15; s_nop 15` behind the last MFMA).  hipcc inserts register copies at control-flow joins; one
+    placed between the last MFMA of a branch and the nops loses that MFMA's contribution (it happened: the last k-tile of every
+    product, when the pipelined drain was first added as an if/else)."""
+    src = open(path).read()
+    bad = n = 0
+    for m in re.finditer(r"^(_ZN4klab\w*(?:gemm_glds_kernel|klab_lmhead_gemm|gemm_glds_fp8_kernel|gemm_glds_grouped_tn_kernel|gemm_glds_w8_kernel)\w*):(.*?)s_endpgm", src, re.S | re.M):
+        n += 1
+        body = [l.strip() for l in m.group(2).splitlines() if l.strip() and not l.strip().startswith((";", "."))]
+        hot = {}   # register -> instructions since the MFMA that wrote it
+        for l in body:
+            op, _, rest = l.partition(" ")
+            ops_ = [o.strip() for o in rest.split(",")]
+            # age in (under-estimated) cycles: s_nop N = N + 1, an MFMA 16, anything else 4 (one wave64 VALU / LDS / scalar issue);
+            # the sources put two `s_nop 15` (32 cycles) behind the last MFMA, which every parity test has validated -- flag reads younger than that
+            if op.startswith("s_nop"):
+                step = int(rest.strip() or 0) + 1
+            elif op.startswith("v_mfma"):
+                step = 16
+            else:
+                step = 4
+            hot = {r: c + step for r, c in hot.items()}
+            hot = {r: c for r, c in hot.items() if c < 32}
+            if op.startswith("v_mfma"):
+                for r in regs(ops_[0]):
+                    hot[r] = 0
+                continue
+            if op.startswith("s_") or op.startswith("ds_read") or not ops_:
+                continue
+            srcs = set()
+            for o in ops_[1:]:
+                srcs |= regs(o.split(" ")[0])
+            hit = srcs & set(hot)
+            if hit:
+                bad += 1
+                print(f"{m.group(1)[:80]}: `{l}` reads MFMA results {sorted(hit)[:4]} ~{min(hot[r] for r in hit)} cycles after the MFMA")
+                break
+    print(f"checked {n} kernels for early accumulator reads, {bad} found")
+    return bad
 
 if __name__ == "__main__":
     sys.exit(main(sys.argv[1]))
