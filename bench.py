@@ -2,7 +2,8 @@
 """Caption-training throughput of the native Swin-V2 -> T5 path on MI355X (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W [--workload caption|cfg3|spanmask|cfg5]
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...; without a launcher in the
+     environment `python bench.py --gpus N` starts those N ranks itself as a child process, or fails -- it never measures one rank)
 
 One step = what ref/train.py:58-67 does per iteration: loss = model(images, src, tgt); loss.backward();
 optimizer.step(); optimizer.zero_grad()  -- forward + backward of MyModel (libklab_mm.so engine), the
@@ -162,12 +163,43 @@ def _traffic(key):
         return None
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` WITHOUT a launcher (no WORLD_SIZE in the environment): start the N ranks ourselves, the way
+    ref/run_scripts/caption/train_with_swin.sh:1 starts the reference (torchrun, one process per GPU), as a CHILD process --
+    this process has not touched the GPU and never will -- relay rank 0's single JSON line and exit with the child's code.
+    A run that cannot start its ranks fails; it never falls back to one rank."""
+    import subprocess
+    avail = torch.cuda.device_count()  # (does not initialise the GPU on this image)
+    if "KLAB_BENCH_DEVICE" not in os.environ and avail < n:
+        print(f"[bench] --gpus {n} but only {avail} GPU(s) visible: refusing to measure fewer ranks than asked for", file=sys.stderr)
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes on this driver
+    print("[bench] no launcher in the environment: starting", n, "ranks:", " ".join(cmd), file=sys.stderr, flush=True)
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    if r.returncode != 0 or len(lines) != 1:
+        print(f"[bench] ranks exited with {r.returncode}, {len(lines)} JSON line(s) on stdout", file=sys.stderr)
+        sys.stderr.write(r.stdout[-2000:])
+        return r.returncode or 3
+    d = json.loads(lines[0])
+    if d.get("n_gpus") != n:
+        print(f"[bench] asked for {n} ranks, the line reports n_gpus={d.get('n_gpus')}", file=sys.stderr)
+        return 4
+    print(lines[0], flush=True)
+    return 0
+
+
 def main():
-    # stdout carries exactly ONE JSON line: everything else that writes to file descriptor 1 while the bench runs (RCCL's
-    # version banner, library notices) is sent to stderr; the descriptor is restored for the final line
-    sys.stdout.flush()
-    _stdout_fd = os.dup(1)
-    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -186,12 +218,21 @@ def main():
                     "while the step is GPU-bound; kept for when it becomes launch-bound)")
     a = ap.parse_args()
     wl = WORKLOADS[a.workload]
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:  # before ANY GPU call of this process
+        sys.exit(self_launch(a.gpus, sys.argv[1:]))
+    # stdout carries exactly ONE JSON line: everything else that writes to file descriptor 1 while the bench runs (RCCL's
+    # version banner, library notices) is sent to stderr; the descriptor is restored for the final line
+    sys.stdout.flush()
+    _stdout_fd = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1 or os.environ.get("KLAB_BENCH_FORCE_DIST") in ("1", "2")  # the latter: rehearse the N>1 code path with one rank
-    if a.gpus != world and dist_on:
+    if a.gpus != world and (dist_on or a.gpus > 1):  # never print n_gpus != --gpus
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     # rehearsal knobs (never set by the driver): KLAB_BENCH_DEVICE pins every rank to one card and KLAB_BENCH_BACKEND=gloo moves the
     # collectives through the host, so that the N > 1 code path (ranks, barrier, reducer, rank-0 JSON) can run on a one-GPU box
@@ -264,7 +305,13 @@ def main():
     dt = time.perf_counter() - t0
     if dist_on and rank == 0:
         print(f"[bench] closing barrier took {(time.perf_counter() - t_sync) * 1e3:.2f} ms", file=sys.stderr, flush=True)
+    rank_ms = None
     if dist_on:
+        # per-rank wall time of the K steps up to the rank's own synchronize (before the closing barrier): the spread shows stragglers
+        own = torch.tensor([(t_sync - t0) / a.steps * 1e3], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(own) for _ in range(dist.get_world_size())]
+        dist.all_gather(allr, own)
+        rank_ms = [round(float(x.item()), 3) for x in allr]
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -302,6 +349,8 @@ def main():
                                      "allreduce_calls_per_step": round(st["calls"] / max(a.steps, 1), 2),
                                      "allreduce_bytes_per_step": int(st["bytes"] / max(a.steps, 1)),
                                      "replicas_in_sync_after_run": in_sync}
+        if rank_ms:
+            out["config"]["rank_ms_per_step"] = {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms}
         # roofline of the kernels that hold the largest shares of GPU time (profiles/*_kernel_stats.csv): live HIP-event
         # durations around each launch on the stream it runs on; algorithmic FLOPs = 2*M*N*K per product
         rl = []

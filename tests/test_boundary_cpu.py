@@ -312,3 +312,15 @@ def test_bench_workloads_follow_the_survey_table():
         assert all(x == 0 for x in row[end + 1:]) and int(tgt[b, 0]) == 32099
         trow = tgt[b].tolist()
         assert 1 in trow and all(x == 0 for x in trow[trow.index(1) + 1:])
+
+
+def test_bench_refuses_to_measure_fewer_ranks_than_asked_for():
+    """`python bench.py --gpus 8` without a launcher and without 8 visible GPUs must fail, never print an n_gpus: 1 line."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "KLAB_BENCH_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
