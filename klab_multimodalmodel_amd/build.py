@@ -44,24 +44,35 @@ def build_library(force=False, verbose=True):
         src, obj = job
         checked = os.path.basename(src) == "gemm.hip"  # hand-scheduled inline-asm loops: the ISA itself is verified (below)
         cmd = [HIPCC] + FLAGS + (["-save-temps=obj"] if checked else []) + ["-x", "hip", "-c", src, "-o", obj]
+        stem = os.path.splitext(os.path.basename(src))[0]
+        if checked:  # stale temporaries of an earlier compile must not be what gets checked
+            for f in os.listdir(OBJDIR):
+                if f.startswith(stem) and f != os.path.basename(obj):
+                    os.remove(os.path.join(OBJDIR, f))
         r = subprocess.run(cmd, capture_output=True, text=True, cwd=OBJDIR)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
         if checked:
             # tools/check_gemm_asm.py on the device assembly of THIS compile: no read of an asm-loaded LDS fragment before its wait,
             # no read of an inline-asm MFMA's result before the pipe has drained (hipcc may place copies at control-flow joins)
-            asm = [os.path.join(OBJDIR, f) for f in os.listdir(OBJDIR) if f.startswith("gemm") and "gfx950" in f and f.endswith(".s")]
+            # (fails CLOSED: this check is the only guard against an inline-asm MFMA result being read early)
+            asm = [os.path.join(OBJDIR, f) for f in os.listdir(OBJDIR) if f.startswith(stem) and "gfx950" in f and f.endswith(".s")]
             tool = os.path.join(ROOT, "tools", "check_gemm_asm.py")
-            if asm and os.path.exists(tool):
-                c = subprocess.run([sys.executable, tool, asm[0]], capture_output=True, text=True)
-                for f in os.listdir(OBJDIR):  # the temporaries are large (tens of MB): keep only objects
-                    if f.startswith("gemm") and f != os.path.basename(obj):
-                        os.remove(os.path.join(OBJDIR, f))
-                if c.returncode != 0:
-                    os.remove(obj)
-                    raise RuntimeError("tools/check_gemm_asm.py rejected the GEMM kernels' assembly:\n" + c.stdout[-3000:])
-                if verbose:
-                    print("ISA check:", "; ".join(c.stdout.strip().splitlines()[-2:]), file=sys.stderr)
+            if len(asm) != 1 or not os.path.exists(tool):
+                os.remove(obj)
+                raise RuntimeError(f"ISA check of {os.path.basename(src)} could not run: device assembly {asm or 'not found'} "
+                                   f"(hipcc -save-temps naming changed?), checker {'present' if os.path.exists(tool) else 'MISSING'}")
+            c = subprocess.run([sys.executable, tool, asm[0]], capture_output=True, text=True)
+            for f in os.listdir(OBJDIR):  # the temporaries are large (tens of MB): keep only objects
+                if f.startswith(stem) and f != os.path.basename(obj):
+                    os.remove(os.path.join(OBJDIR, f))
+            import re
+            nk = re.search(r"checked (\d+) kernels", c.stdout)
+            if c.returncode != 0 or not nk or int(nk.group(1)) < 1:
+                os.remove(obj)
+                raise RuntimeError("tools/check_gemm_asm.py rejected the GEMM kernels' assembly (or checked nothing):\n" + c.stdout[-3000:] + c.stderr[-1000:])
+            if verbose:
+                print("ISA check:", "; ".join(c.stdout.strip().splitlines()[-2:]), file=sys.stderr)
         if verbose:
             print("compiled", os.path.basename(src), file=sys.stderr)
 

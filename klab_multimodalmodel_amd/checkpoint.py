@@ -77,6 +77,8 @@ class AsyncCheckpointer:
         # 1. everything that creates tensors on the CURRENT stream first (FusedAdam.state_dict() clones its moments, other
         #    optimizers may build theirs lazily) ...
         flat = _flat_state(optimizer) if optimizer is not None else None
+        if hasattr(core, "_join_pending_update"):
+            core._join_pending_update()  # an in-backward optimizer update on its own stream still writes the weights
         t_sd = core.transformer.state_dict() if rank == 0 else None
         i_sd = core.image_model.state_dict() if rank == 0 and getattr(core.args, "image_model_train", False) else None
         o_sd = optimizer.state_dict() if rank == 0 and optimizer is not None and flat is None else None

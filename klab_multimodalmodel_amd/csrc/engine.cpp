@@ -1180,7 +1180,16 @@ extern "C" int klab_engine_bind(klab_engine* e, int B, int Ls, int Lt, void* wor
   if (e->cfg.train_swin && !swin_grads) return KLAB_ERR_BADARG;
   // a rebind (new batch shape / device): kernels and captured graphs of the previous binding may still be in flight and
   // address the old workspace, which the caller releases after this call
-  if (e->bound) { e->bound = false; drain_engine(e); }
+  // The dropout RNG of the model (base seed, forwards since seeding) lives in device words of the binding's workspace; a rebind
+  // must not restart it -- the reference loop pads every batch to its longest row (ref/train.py:56-57), i.e. rebinds almost every
+  // step, and a restarted counter would replay the masks of step 1 each time.  Carried over to the new workspace below.
+  uint32_t carry[3] = {0, 0, 0};
+  bool carry_rng = false;
+  if (e->bound) {
+    e->bound = false;
+    drain_engine(e);
+    if (e->seed_set && e->seed_dev) carry_rng = hipMemcpy(carry, e->seed_dev, sizeof(carry), hipMemcpyDeviceToHost) == hipSuccess;
+  }
   const size_t need = plan_workspace(e, workspace, B, Ls, Lt);
   if (need > ws_bytes) return KLAB_ERR_BADARG;
   const void* const* src[3] = {swin_params, lang_params, main_params};
@@ -1329,6 +1338,11 @@ extern "C" int klab_engine_bind(klab_engine* e, int B, int Ls, int Lt, void* wor
     g = klab_engine::GraphSlot();
   }
   e->seed_set = false;
+  if (carry_rng) {  // (stream-ordered behind the memset above; seed_base is unchanged, so the next forward keeps the counter)
+    RC((int)hipMemcpyAsync(e->seed_dev, carry, sizeof(carry), hipMemcpyHostToDevice, hs));
+    RC((int)hipStreamSynchronize(hs));  // `carry` is a stack buffer
+    e->seed_set = true;
+  }
   if (!e->side) {
     {  // experiment knob: KLAB_SIDE_PRIO=low|high gives the side stream (weight gradients, language encoder) another priority
       const char* pv = getenv("KLAB_SIDE_PRIO");

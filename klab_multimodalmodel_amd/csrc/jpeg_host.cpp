@@ -57,6 +57,7 @@ struct Comp { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0; int bw = 0, bh =
 struct Parsed {
   int width = 0, height = 0, ncomp = 0, precision = 8, hmax = 1, vmax = 1, mcus_x = 0, mcus_y = 0;
   bool progressive = false, have_sof = false, jfif = false, adobe = false;
+  int n_scans = 0;
   int adobe_transform = -1;
   int restart_interval = 0;
   Comp comp[4];
@@ -172,6 +173,10 @@ int parse(const uint8_t* data, size_t n, Parsed& P, int16_t* coefs) {
         P.comp[c].tq = s[8 + 3 * c] & 3;
         if (P.comp[c].h < 1 || P.comp[c].h > 4 || P.comp[c].v < 1 || P.comp[c].v > 4) return KLAB_ERR_BADARG;
       }
+      // untrusted files (RedCaps images come from the web): refuse frames beyond Pillow's own decompression-bomb limit
+      // (Image.MAX_IMAGE_PIXELS * 2 = 178,956,970 pixels raises DecompressionBombError in the reference's Image.open) before
+      // anybody sizes a buffer from the header
+      if (P.width < 1 || P.height < 1 || (long long)P.width * P.height > 178956970LL) return KLAB_ERR_UNSUPPORTED;
       P.have_sof = true;
       const int rc = geometry(P);
       if (rc) return rc;
@@ -212,6 +217,8 @@ int parse(const uint8_t* data, size_t n, Parsed& P, int16_t* coefs) {
       if (!P.have_sof) return KLAB_ERR_BADARG;
       if (!coefs) return KLAB_OK;  // header only
       if (P.precision != 8) return KLAB_ERR_UNSUPPORTED;
+      if (len < 6) return KLAB_ERR_BADARG;  // (a segment cut right behind its length field: s == se, nothing to read)
+      if (++P.n_scans > 1024) return KLAB_ERR_UNSUPPORTED;  // a progressive file needs a few dozen scans; bound the work a crafted one can ask for
       const int ns = s[0];
       if (ns < 1 || ns > P.ncomp || len < 6 + 2 * ns) return KLAB_ERR_BADARG;
       const int Ss = s[1 + 2 * ns], Se = s[2 + 2 * ns], Ah = s[3 + 2 * ns] >> 4, Al = s[3 + 2 * ns] & 15;

@@ -221,7 +221,6 @@ class MyModel(nn.Module):
         self._pending_reduce = None  # klab DDP(overlap_optimizer=True): reducer whose last all-reduces are not joined yet
         self.use_graph = os.environ.get("KLAB_GRAPH", "0") == "1"  # hipGraph replay of the engine's launch sequences
         self._seed_base = torch.initial_seed() & 0xFFFFFFFF
-        self._seed_ctr = 0
         self._pending_rng = None  # (base, counter) restored by load_checkpoint, applied at the next bind
         self._frozen_fp = None
         self._train_fp = None  # version fingerprint of the trainable T5 right after a klab FusedAdam step (bf16 copies current)
@@ -395,7 +394,19 @@ class MyModel(nn.Module):
         start = torch.full((B, 1), cfg.decoder_start_token_id, dtype=torch.int64, device=src.device)
         return torch.cat([start, tgt], dim=1)
 
+    def _join_pending_update(self):
+        """an optimizer update still running on its own stream (optim.FusedAdam(step_in_backward=True)) writes the weights:
+        anything that reads them on the current stream waits for it first"""
+        if self._pending_opt_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._pending_opt_stream)
+            self._pending_opt_stream = None
+
+    def state_dict(self, *a, **k):
+        self._join_pending_update()
+        return super().state_dict(*a, **k)
+
     def save(self, result_name="best.pth"):
+        self._join_pending_update()
         result_path = os.path.join(self.args.result_dir, result_name)
         checkpoints = {'transformer': self.transformer.state_dict()}
         if self.args.image_model_train:

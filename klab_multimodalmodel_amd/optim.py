@@ -51,6 +51,12 @@ class FusedAdam(Optimizer):
         if any, is enqueued): update segment 0 underneath the rest of the backward"""
         if seg != 0 or self._fallback is not None or self._m is None or len(self.param_groups) != 1:
             return
+        if self._bw_token is not None:
+            # a second backward() before step(): gradient accumulation (ref/train.py --accumulation_steps > 1).  The first
+            # micro-batch's gradients were already applied to segment 0 underneath its backward -- the update is not what Adam
+            # would have done with the accumulated sum.  The contract is one backward per step: say so instead of training wrong.
+            raise RuntimeError("FusedAdam(step_in_backward=True) supports exactly one backward() per step(); with gradient "
+                               "accumulation construct it with step_in_backward=False")
         g = self.param_groups[0]
         if g["amsgrad"] or g["maximize"] or self._owner is None or self._owner() is not model:
             return

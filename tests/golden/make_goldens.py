@@ -6,10 +6,9 @@ config-constructed, seeded random-init HuggingFace weights saved to a scratch di
 (SURVEY.md §8c), runs ``MyModel.forward`` + ``loss.backward()`` in eval mode (dropout off, the
 reference's own parity-capable mode) and stores inputs / weights / outputs / grads as ``.npz``
 fixtures next to this file.  Only the *outputs* of this script travel to the GPU box; the
-reference's sources never do.  It also records the argparse defaults (ref/modules/config.py:6-22).  The span-mask loader
-(ref/modules/loader.py:56-72) cannot be imported here (torchvision / pycocotools are absent and
-are NOT stubbed); its fixture ``spanmask.json`` holds the one input/output pair the survey recorded
-from the reference.
+reference's sources never do.  It also records the argparse defaults (ref/modules/config.py:6-22).  The span-mask loader's
+vectors (ref/modules/loader.py:56-77) are produced by ``make_spanmask_goldens.py`` next to this file, which runs the
+reference's own ``RedCapsDatasetLoader.__getitem__`` (45 ``(seed, caption) -> (src, tgt)`` pairs in ``spanmask.json``).
 
 Run:  python tests/golden/make_goldens.py      (needs /root/reference + transformers; CPU only)
 """

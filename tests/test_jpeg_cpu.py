@@ -54,6 +54,17 @@ def test_header_info_and_unsupported_files():
         ops.jpeg_entropy_decode_batch([buf.getvalue()])
     with pytest.raises(ValueError):
         ops.jpeg_read_info(b"not a jpeg at all")
+    # a decompression bomb: ~200 bytes declaring 65535 x 65535 must be refused from the header, before anything is sized from it
+    # (the reference's Image.open raises DecompressionBombError above 178,956,970 pixels)
+    buf = io.BytesIO()
+    img.save(buf, "JPEG", quality=80)
+    d = bytearray(buf.getvalue())
+    i = bytes(d).find(b"\xff\xc0")
+    d[i + 5:i + 9] = bytes([0xFF, 0xFF, 0xFF, 0xFF])
+    with pytest.raises((NotImplementedError, ValueError, RuntimeError)):
+        ops.jpeg_read_info(bytes(d))
+    with pytest.raises((NotImplementedError, ValueError, RuntimeError)):
+        ops.jpeg_entropy_decode_batch([bytes(d)])
     # truncated entropy data decodes (zeros are fed, as libjpeg does) rather than reading out of bounds
     buf = io.BytesIO()
     img.save(buf, "JPEG", quality=80)
@@ -106,6 +117,19 @@ def test_host_decoder_survives_mutated_files(tmp_path):
             f.write_bytes(m.tobytes())
             files.append(str(f))
             k += 1
+    # deterministic: every seed cut right behind the length field of each of its marker segments (a header parser that reads a
+    # segment's first byte before checking its length walks one byte past the buffer exactly there)
+    for d in seeds:
+        i = 2
+        while i + 4 <= len(d) and d[i] == 0xFF:
+            mk = d[i + 1]
+            f = tmp_path / f"m{k}.jpg"
+            f.write_bytes(d[:i + 4])
+            files.append(str(f))
+            k += 1
+            if mk == 0xDA:
+                break
+            i += 2 + ((d[i + 2] << 8) | d[i + 3])
     assert len(files) > 1000
     for i in range(0, len(files), 400):
         r = subprocess.run([str(exe)] + files[i:i + 400], capture_output=True, text=True, timeout=300)

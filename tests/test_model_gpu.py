@@ -540,6 +540,41 @@ def test_checkpoint_resume_with_fused_adam(tmp_path):
 
 
 @pytest.mark.gpu
+def test_dropout_stream_survives_rebinds():
+    """The reference loop pads every batch to its longest row (ref/train.py:56-57), so (Ls, Lt) -- and with it the engine's
+    binding -- changes almost every step.  The dropout RNG (base seed + forward counter) belongs to the model, not to the
+    binding: alternating two shapes must keep counting (different masks every step), and a restored (base, counter) must
+    continue the same stream across the next shape change."""
+    def make():
+        m, g = build("tiny_a", torch.float32, False)
+        m._seed_base = 4321
+        m.transformer.train()
+        return m, g
+
+    def fwd(m, g, short):
+        inp = g["inputs"]
+        tgt = inp["tgt_ids"][:, :5] if short else inp["tgt_ids"]
+        src = inp["src_ids"][:, :4] if short else inp["src_ids"]
+        with torch.no_grad():
+            return float(m({"pixel_values": inp["pixel_values"].cuda()}, {"input_ids": src.contiguous().cuda()}, {"input_ids": tgt.contiguous().cuda()}))
+
+    m0, g = make()
+    seq = [fwd(m0, g, k % 2 == 1) for k in range(6)]  # shapes A B A B A B: five rebinds
+    assert m0._engine.get_rng() == (4321, 6)
+    assert len({round(x, 7) for x in seq[0::2]}) == 3 and len({round(x, 7) for x in seq[1::2]}) == 3, seq  # same input, new masks
+    m1, g = make()
+    for k in range(2):
+        fwd(m1, g, k % 2 == 1)
+    base, ctr = m1._engine.get_rng()
+    assert (base, ctr) == (4321, 2)
+    m2, g = make()
+    m2._seed_base = base
+    m2._pending_rng = (base, ctr)  # what load_checkpoint does before the first forward
+    rest = [fwd(m2, g, k % 2 == 1) for k in range(2, 6)]
+    for a, b in zip(seq[2:], rest):
+        assert abs(a - b) <= 1e-6 * abs(a), (seq, rest)
+
+
 def test_resume_continues_the_dropout_stream(tmp_path):
     """true resume with dropout ON: the engine's device-side RNG (base seed + forward counter) and the model's seed base are
     part of the checkpoint, so 2 steps + save + load into a fresh model + 2 steps reproduce 4 uninterrupted train-mode steps
