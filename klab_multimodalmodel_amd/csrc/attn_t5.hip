@@ -130,17 +130,22 @@ __global__ __launch_bounds__(256) void t5_attn_fwd_kernel(AttnP p) {
   }
 }
 
+// Backward.  One workgroup per (batch, head).  The keys are visited in chunks of `kc` rows (kc = Lk whenever K, V and their f32
+// gradient accumulators fit the 160 KB of LDS together; T5-large's cross-attention in fp32 parity mode, Lk = 153 at dk = 64, does
+// not): per chunk, K / V rows are staged, every query tile is swept (P from the saved log-sum-exp, so no row needs its other
+// chunks), dK / dV of the chunk are complete and stored, and dQ -- a sum over ALL keys -- is written by the first chunk and
+// read-modify-written by the later ones (the same thread owns the same element every time: no race, fixed summation order).
 template <typename T>
-__global__ __launch_bounds__(256) void t5_attn_bwd_kernel(AttnP p) {
+__global__ __launch_bounds__(256) void t5_attn_bwd_kernel(AttnP p, int kc) {
   constexpr int VEC = Vec16<T>::N;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int Lk = p.Lk, dk = p.dk, Lq = p.Lq;
-  const int kst = dk + VEC, pst = Lk + 1;
+  const int kst = dk + VEC, pst = kc + 1;
   T* Ks = reinterpret_cast<T*>(smem);
-  T* Vs = Ks + (size_t)Lk * kst;
-  float* dKs = reinterpret_cast<float*>(Vs + (size_t)Lk * kst);
-  float* dVs = dKs + (size_t)Lk * dk;
-  float* Qs = dVs + (size_t)Lk * dk;
+  T* Vs = Ks + (size_t)kc * kst;
+  float* dKs = reinterpret_cast<float*>(Vs + (size_t)kc * kst);
+  float* dVs = dKs + (size_t)kc * dk;
+  float* Qs = dVs + (size_t)kc * dk;
   float* dOs = Qs + TQ * dk;
   float* Ps = dOs + TQ * dk;
   float* dSs = Ps + TQ * pst;
@@ -149,96 +154,108 @@ __global__ __launch_bounds__(256) void t5_attn_bwd_kernel(AttnP p) {
   const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const DropCtx dc = drop_slab(make_drop(p.seed, p.tag, p.p), (uint32_t)(b * p.H + h));
-
-  stage_kv<T>(reinterpret_cast<const T*>(p.k), p.ldk, b, h, Lk, dk, Ks, kst);
-  stage_kv<T>(reinterpret_cast<const T*>(p.v), p.ldv, b, h, Lk, dk, Vs, kst);
-  for (int idx = tid; idx < Lk * dk; idx += 256) { dKs[idx] = 0.f; dVs[idx] = 0.f; }
   const T* qg = reinterpret_cast<const T*>(p.q);
   const T* dog = reinterpret_cast<const T*>(p.dctx);
   const T* og = reinterpret_cast<const T*>(p.ctx);
   T* dqg = reinterpret_cast<T*>(p.dq);
-
-  for (int q0 = 0; q0 < Lq; q0 += TQ) {
-    __syncthreads();  // previous tile fully consumed (and the initial staging visible)
-    for (int idx = tid; idx < TQ * dk; idx += 256) {
-      const int i = idx / dk, c = idx % dk, qi = q0 + i;
-      float qv = 0.f, dov = 0.f;
-      if (qi < Lq) {
-        qv = to_f32(qg[((long)b * Lq + qi) * p.ldq + (long)h * dk + c]);
-        dov = to_f32(dog[((long)b * Lq + qi) * p.lddo + (long)h * dk + c]);
-      }
-      Qs[idx] = qv; dOs[idx] = dov;
-    }
-    for (int i = wave; i < TQ; i += 4) {
-      const int qi = q0 + i;
-      float acc = 0.f;
-      if (qi < Lq) {
-        for (int c = lane; c < dk; c += 64)
-          acc += to_f32(dog[((long)b * Lq + qi) * p.lddo + (long)h * dk + c]) * to_f32(og[((long)b * Lq + qi) * p.ldo + (long)h * dk + c]);
-      }
-      acc = wave_sum(acc);
-      if (lane == 0) {
-        delta[i] = acc;
-        lses[i] = qi < Lq ? p.lse[((long)b * p.H + h) * Lq + qi] : 0.f;
-      }
-    }
-    __syncthreads();
-
-    for (int idx = tid; idx < TQ * Lk; idx += 256) {
-      const int i = idx / Lk, j = idx % Lk, qi = q0 + i;
-      float pd = 0.f, ds = 0.f;
-      if (qi < Lq && !(p.causal && j > qi)) {
-        float s = 0.f, dpd = 0.f;
-        const T* kr = Ks + j * kst;
-        const T* vr = Vs + j * kst;
-        const float* qr = Qs + i * dk;
-        const float* dor = dOs + i * dk;
-        for (int c = 0; c < dk; c += VEC) {
-          float kv[VEC], vv[VEC];
-          load_vec_f32<T>(kr + c, kv);
-          load_vec_f32<T>(vr + c, vv);
-#pragma unroll
-          for (int u = 0; u < VEC; ++u) { s += qr[c + u] * kv[u]; dpd += dor[c + u] * vv[u]; }
-        }
-        if (p.bias) s += p.bias[((long)h * Lq + qi) * Lk + j];
-        const float pr = __expf(s - lses[i]);
-        const float mlt = drop_mult32(dc, (uint32_t)qi * (uint32_t)Lk + j);
-        pd = pr * mlt;
-        ds = pr * (dpd * mlt - delta[i]);
-        if (p.dbias) atomicAdd(p.dbias + ((long)h * Lq + qi) * Lk + j, ds);
-      }
-      Ps[i * pst + j] = pd;
-      dSs[i * pst + j] = ds;
-    }
-    __syncthreads();
-
-    for (int idx = tid; idx < Lk * dk; idx += 256) {
-      const int j = idx / dk, c = idx % dk;
-      float av = 0.f, ak = 0.f;
-#pragma unroll 4
-      for (int i = 0; i < TQ; ++i) {
-        av += Ps[i * pst + j] * dOs[i * dk + c];
-        ak += dSs[i * pst + j] * Qs[i * dk + c];
-      }
-      dVs[idx] += av;
-      dKs[idx] += ak;
-    }
-    for (int idx = tid; idx < TQ * dk; idx += 256) {
-      const int i = idx / dk, c = idx % dk, qi = q0 + i;
-      if (qi >= Lq) continue;
-      float a = 0.f;
-      const float* dsr = dSs + i * pst;
-      for (int j = 0; j < Lk; ++j) a += dsr[j] * to_f32(Ks[j * kst + c]);
-      dqg[((long)b * Lq + qi) * p.lddq + (long)h * dk + c] = from_f32<T>(a);
-    }
-  }
-  __syncthreads();
   T* dkg = reinterpret_cast<T*>(p.dkk);
   T* dvg = reinterpret_cast<T*>(p.dv);
-  for (int idx = tid; idx < Lk * dk; idx += 256) {
-    const int j = idx / dk, c = idx % dk;
-    dkg[((long)b * Lk + j) * p.lddk + (long)h * dk + c] = from_f32<T>(dKs[idx]);
-    dvg[((long)b * Lk + j) * p.lddv + (long)h * dk + c] = from_f32<T>(dVs[idx]);
+  const int cpr = dk / VEC;
+  using V16 = typename Vec16<T>::type;
+
+  for (int kb = 0; kb < Lk; kb += kc) {
+    const int Lc = Lk - kb < kc ? Lk - kb : kc;
+    __syncthreads();  // the previous chunk's images are fully consumed
+    for (int ch = tid; ch < Lc * cpr; ch += 256) {
+      const int j = ch / cpr, c = (ch % cpr) * VEC;
+      const long row = (long)b * Lk + kb + j;
+      *reinterpret_cast<V16*>(Ks + j * kst + c) = *reinterpret_cast<const V16*>(reinterpret_cast<const T*>(p.k) + row * p.ldk + (long)h * dk + c);
+      *reinterpret_cast<V16*>(Vs + j * kst + c) = *reinterpret_cast<const V16*>(reinterpret_cast<const T*>(p.v) + row * p.ldv + (long)h * dk + c);
+    }
+    for (int idx = tid; idx < Lc * dk; idx += 256) { dKs[idx] = 0.f; dVs[idx] = 0.f; }
+
+    for (int q0 = 0; q0 < Lq; q0 += TQ) {
+      __syncthreads();  // previous tile fully consumed (and the chunk's staging visible)
+      for (int idx = tid; idx < TQ * dk; idx += 256) {
+        const int i = idx / dk, c = idx % dk, qi = q0 + i;
+        float qv = 0.f, dov = 0.f;
+        if (qi < Lq) {
+          qv = to_f32(qg[((long)b * Lq + qi) * p.ldq + (long)h * dk + c]);
+          dov = to_f32(dog[((long)b * Lq + qi) * p.lddo + (long)h * dk + c]);
+        }
+        Qs[idx] = qv; dOs[idx] = dov;
+      }
+      for (int i = wave; i < TQ; i += 4) {
+        const int qi = q0 + i;
+        float acc = 0.f;
+        if (qi < Lq) {
+          for (int c = lane; c < dk; c += 64)
+            acc += to_f32(dog[((long)b * Lq + qi) * p.lddo + (long)h * dk + c]) * to_f32(og[((long)b * Lq + qi) * p.ldo + (long)h * dk + c]);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) {
+          delta[i] = acc;
+          lses[i] = qi < Lq ? p.lse[((long)b * p.H + h) * Lq + qi] : 0.f;
+        }
+      }
+      __syncthreads();
+
+      for (int idx = tid; idx < TQ * Lc; idx += 256) {
+        const int i = idx / Lc, j = idx % Lc, qi = q0 + i, kj = kb + j;
+        float pd = 0.f, ds = 0.f;
+        if (qi < Lq && !(p.causal && kj > qi)) {
+          float s = 0.f, dpd = 0.f;
+          const T* kr = Ks + j * kst;
+          const T* vr = Vs + j * kst;
+          const float* qr = Qs + i * dk;
+          const float* dor = dOs + i * dk;
+          for (int c = 0; c < dk; c += VEC) {
+            float kv[VEC], vv[VEC];
+            load_vec_f32<T>(kr + c, kv);
+            load_vec_f32<T>(vr + c, vv);
+#pragma unroll
+            for (int u = 0; u < VEC; ++u) { s += qr[c + u] * kv[u]; dpd += dor[c + u] * vv[u]; }
+          }
+          if (p.bias) s += p.bias[((long)h * Lq + qi) * Lk + kj];
+          const float pr = __expf(s - lses[i]);
+          const float mlt = drop_mult32(dc, (uint32_t)qi * (uint32_t)Lk + kj);
+          pd = pr * mlt;
+          ds = pr * (dpd * mlt - delta[i]);
+          if (p.dbias) atomicAdd(p.dbias + ((long)h * Lq + qi) * Lk + kj, ds);
+        }
+        Ps[i * pst + j] = pd;
+        dSs[i * pst + j] = ds;
+      }
+      __syncthreads();
+
+      for (int idx = tid; idx < Lc * dk; idx += 256) {
+        const int j = idx / dk, c = idx % dk;
+        float av = 0.f, ak = 0.f;
+#pragma unroll 4
+        for (int i = 0; i < TQ; ++i) {
+          av += Ps[i * pst + j] * dOs[i * dk + c];
+          ak += dSs[i * pst + j] * Qs[i * dk + c];
+        }
+        dVs[idx] += av;
+        dKs[idx] += ak;
+      }
+      for (int idx = tid; idx < TQ * dk; idx += 256) {
+        const int i = idx / dk, c = idx % dk, qi = q0 + i;
+        if (qi >= Lq) continue;
+        float a = 0.f;
+        const float* dsr = dSs + i * pst;
+        for (int j = 0; j < Lc; ++j) a += dsr[j] * to_f32(Ks[j * kst + c]);
+        T* dst = dqg + ((long)b * Lq + qi) * p.lddq + (long)h * dk + c;
+        if (kb > 0) a += to_f32(*dst);  // (this thread wrote the element for the earlier chunks)
+        *dst = from_f32<T>(a);
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < Lc * dk; idx += 256) {
+      const int j = idx / dk, c = idx % dk;
+      dkg[((long)b * Lk + kb + j) * p.lddk + (long)h * dk + c] = from_f32<T>(dKs[idx]);
+      dvg[((long)b * Lk + kb + j) * p.lddv + (long)h * dk + c] = from_f32<T>(dVs[idx]);
+    }
   }
 }
 
@@ -312,17 +329,26 @@ extern "C" int klab_t5_attn_bwd(const klab_attn_args* a, void* stream) {
   if (a->score_scale || a->bias_mod) return KLAB_ERR_UNSUPPORTED;  // matrix-core kernel only (Swin window attention backward)
   const size_t es = a->dtype == KLAB_BF16 ? 2 : 4;
   const int vec = a->dtype == KLAB_BF16 ? 8 : 4;
-  const size_t lds = 2 * (size_t)a->Lk * (a->dk + vec) * es + 2 * (size_t)a->Lk * a->dk * 4 + 2 * (size_t)TQ * a->dk * 4 +
-                     2 * (size_t)TQ * (a->Lk + 1) * 4 + 2 * TQ * 4;
+  auto lds_for = [&](int kc) {
+    return 2 * (size_t)kc * (a->dk + vec) * es + 2 * (size_t)kc * a->dk * 4 + 2 * (size_t)TQ * a->dk * 4 + 2 * (size_t)TQ * (kc + 1) * 4 + 2 * TQ * 4;
+  };
+  int kc = a->Lk;  // keys per chunk: all of them when the images fit, else the largest multiple of 16 that does
+  const size_t budget = 150 * 1024;
+  if (lds_for(kc) > budget) {
+    kc = 16;
+    while (kc + 16 < a->Lk && lds_for(kc + 16) <= budget) kc += 16;
+    if (lds_for(kc) > budget) return KLAB_ERR_UNSUPPORTED;
+  }
+  const size_t lds = lds_for(kc);
   AttnP p = to_p(a);
   dim3 grid(a->B * a->H);
   hipStream_t s = (hipStream_t)stream;
   if (a->dtype == KLAB_BF16) {
     rc = set_lds(t5_attn_bwd_kernel<bf16_t>, lds); if (rc) return rc;
-    hipLaunchKernelGGL(t5_attn_bwd_kernel<bf16_t>, grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL(t5_attn_bwd_kernel<bf16_t>, grid, dim3(256), lds, s, p, kc);
   } else {
     rc = set_lds(t5_attn_bwd_kernel<float>, lds); if (rc) return rc;
-    hipLaunchKernelGGL(t5_attn_bwd_kernel<float>, grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL(t5_attn_bwd_kernel<float>, grid, dim3(256), lds, s, p, kc);
   }
   KLAB_LAUNCH_CHECK();
   return KLAB_OK;

@@ -2,7 +2,8 @@
 reference itself (tests/golden/*.npz) and against the CPU oracle: loss, tower outputs, every gradient.
 
 Stated tolerances (SURVEY §8c): fp32 engine -- loss rel <= 1e-5, grad rel-L2 <= 1e-4 per tensor;
-bf16 engine -- loss rel <= 2e-3, overall grad cosine >= 0.99 and per-tensor cosine >= 0.9.
+bf16 engine -- loss rel <= 2e-3, overall grad cosine >= 0.99, per-tensor cosine >= 0.97, and rel-L2 <= 2 x the oracle's
+own bf16 error on the same batch (overall and per tensor).
 """
 import math
 import os
@@ -72,24 +73,61 @@ def test_fp32_engine_matches_reference(name, train_swin):
     print(name, train_swin, "loss", loss.item(), "worst grad", worst)
 
 
+def _oracle_bf16_cast_error(g):
+    """The oracle's OWN bf16 error on this batch (SURVEY §8c yardstick): the same CPU restatement with every weight, input and
+    activation in bf16, against the reference goldens.  Returns (loss rel error, {tensor name: rel-L2}, overall rel-L2)."""
+    from oracle import swin_t5_oracle as O
+    dt = torch.bfloat16
+    sds = {m: {k: (v.to(dt) if v.is_floating_point() else v) for k, v in g["sds"][m].items()} for m in g["sds"]}
+    main = {k: v.clone().requires_grad_(True) for k, v in sds["main"].items()}
+    swin = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sds["swin"].items()}
+    inp = g["inputs"]
+    loss = O.mymodel_forward(swin, sds["lang"], main, g["swin_cfg"], g["t5_cfg"], g["t5_cfg"], inp["pixel_values"].to(dt), inp["src_ids"],
+                             inp["tgt_ids"], training=False, image_model_train=True)
+    loss.backward()
+    per, a, b = {}, [], []
+    for mname, src in (("main", main), ("swin", swin)):
+        for k, ref in g["grads"][mname].items():
+            if src[k].grad is None:
+                continue
+            got = src[k].grad.float()
+            per[(mname, k)] = rel_l2(got, ref)
+            a.append(got.flatten())
+            b.append(ref.flatten())
+    return abs(float(loss.detach()) - g["loss"]) / abs(g["loss"]), per, rel_l2(torch.cat(a), torch.cat(b))
+
+
 @pytest.mark.parametrize("name", ["tiny_a", "tiny_b", "tiny_c", "tiny_d"])
 def test_bf16_engine_within_stated_tolerance(name):
+    """SURVEY §8(c), bf16 kernels: loss rel <= 2e-3, gradient cosine >= 0.99 AND rel-L2 <= 2 x the oracle's own bf16 error on
+    the same batch -- overall and per tensor (the per-tensor bound gets the overall oracle error as a floor: a tensor the bf16
+    oracle happens to hit exactly does not set a zero bar)."""
     m, g = build(name, torch.bfloat16, True)
     m.transformer.eval()
     loss = run(m, g)
     assert abs(loss.item() - g["loss"]) <= 2e-3 * abs(g["loss"])
     loss.backward()
-    a, b = [], []
+    _e_loss, e_per, e_all = _oracle_bf16_cast_error(g)
+    a, b, viol = [], [], []
+    worst = (1.0, "")
     for mname, tree in (("main", m.transformer), ("swin", m.image_model)):
         for k, ref in g["grads"][mname].items():
             got = tree.get_parameter(k).grad.cpu()
             if float(ref.norm()) > 1e-6 * ref.numel() ** 0.5:
-                assert cosine(got, ref) > 0.9, (mname, k, cosine(got, ref))
+                c = cosine(got, ref)
+                worst = min(worst, (c, k))
+                bound = 2 * max(e_per.get((mname, k), 0.0), e_all)
+                if c <= 0.97 or rel_l2(got, ref) > bound:
+                    viol.append((mname, k, "cosine", round(c, 4), "rel-L2", round(rel_l2(got, ref), 4), "bound", round(bound, 4)))
             a.append(got.flatten())
             b.append(ref.flatten())
     c = cosine(torch.cat(a), torch.cat(b))
+    r = rel_l2(torch.cat(a), torch.cat(b))
+    print(name, "bf16 loss", loss.item(), "ref", g["loss"], "grad cosine", c, "rel-L2", r, "oracle's own bf16 rel-L2", e_all,
+          "worst per-tensor cosine", worst)
+    assert not viol, viol
     assert c > 0.99, c
-    print(name, "bf16 loss", loss.item(), "ref", g["loss"], "grad cosine", c, "rel-L2", rel_l2(torch.cat(a), torch.cat(b)))
+    assert r <= 2 * e_all, (r, e_all)
 
 
 def test_eval_loss_is_repeatable_and_no_grad_works():
@@ -897,7 +935,61 @@ def test_large_window_swin_matches_oracle(dtype, loss_tol, cos_min):
 
 
 @pytest.mark.gpu
-def test_configs4_architecture_runs_at_full_width():
+@pytest.mark.parametrize("window,dtype,train_swin", [(8, torch.float32, True), (8, torch.bfloat16, True), (8, torch.bfloat16, False),
+                                                     (16, torch.float32, True), (16, torch.bfloat16, True), (16, torch.bfloat16, False)])
+def test_reference_default_window_geometry_matches_oracle(window, dtype, train_swin):
+    """The reference's LITERAL default tower geometry (ref/modules/config.py:6-11: `swinv2-base-patch4-window8-256`; the
+    `window16-256` checkpoint the CLI also accepts): 256 px, patch 4 -> 64x64 tokens.  Window 8: n = 64 tokens = exactly the
+    one-tile limit of the small-window kernels, shifted by 4 in stages 0-2, R = w = 8 in stage 3.  Window 16: n = 256 (the
+    streaming kernels) in stages 0-1, R = w in stage 2, window clamped to 8 in stage 3 (HF/swinv2:615-618).  Depth and width cut
+    (C = 32, head dim 32 as in every named checkpoint) so that the CPU oracle finishes in seconds; frozen (the fused frozen-tower
+    kernels at n = 64) and unfrozen towers; loss, the tower's output rows and every gradient against the oracle."""
+    from klab_multimodalmodel_amd.engine import SwinConfig, T5Config
+    from klab_multimodalmodel_amd.models.model import MyModel
+    sw = SwinConfig(image_size=256, embed_dim=32, depths=(2, 2, 2, 2), num_heads=(1, 2, 4, 8), window_size=window)
+    t5 = T5Config(vocab_size=512, d_model=256, d_kv=32, num_heads=4, d_ff=512, num_layers=2)
+    args = types.SimpleNamespace(result_dir="/tmp", language_model_name="-", image_model_name="-", image_model_train=train_swin,
+                                 transformer_model_name="-")
+    m = MyModel(args, _configs=(sw, t5, t5), _seed=31 + window, dtype=dtype)
+    O, sc, lc, mc, (ssd, lsd, msd) = _oracle_from_model(m)
+    m = m.to("cuda")
+    m.transformer.eval()
+    g = torch.Generator().manual_seed(5)
+    B, Ls, Lt = 2, 5, 9
+    pix = torch.randn(B, 3, 256, 256, generator=g)
+    src = torch.randint(2, 500, (B, Ls), generator=g)
+    tgt = torch.randint(2, 500, (B, Lt), generator=g)
+    loss = m({"pixel_values": pix.cuda()}, {"input_ids": src.cuda()}, {"input_ids": tgt.cuda()})
+    loss.backward()
+    msd = {k: v.requires_grad_(True) for k, v in msd.items()}
+    if train_swin:
+        ssd = {k: (v.requires_grad_(True) if v.is_floating_point() else v) for k, v in ssd.items()}
+    torch.set_num_threads(8)
+    ref, parts = O.mymodel_forward(ssd, lsd, msd, sc, lc, mc, pix, src, tgt, training=False, image_model_train=train_swin, return_parts=True)
+    ref.backward()
+    f32 = dtype == torch.float32
+    assert abs(loss.item() - float(ref)) <= (3e-5 if f32 else 3e-3) * abs(float(ref)), (loss.item(), float(ref))
+    cat = torch.cat([parts["image_embeddings"], parts["language_embeddings"]], dim=1).detach()
+    got = m._engine.buffer("encoder_input").float().cpu().view(B, -1, cat.shape[-1])
+    assert rel_l2(got, cat) < (2e-5 if f32 else 2e-2), rel_l2(got, cat)
+    trees = [(m.transformer, msd, "t5")] + ([(m.image_model, ssd, "swin")] if train_swin else [])
+    for tree, sd, name in trees:
+        a, b = [], []
+        for k, p in tree.named_parameters():
+            if p.grad is None or sd[k].grad is None:
+                continue
+            if f32 and float(sd[k].grad.norm()) > 1e-7:
+                assert rel_l2(p.grad.cpu(), sd[k].grad) < 2e-3, (name, k, rel_l2(p.grad.cpu(), sd[k].grad))
+            a.append(p.grad.cpu().flatten())
+            b.append(sd[k].grad.flatten())
+        c = cosine(torch.cat(a), torch.cat(b))
+        print("ref-default geometry w", window, dtype, "train_swin", train_swin, name, "grad cosine", c, "rel-L2", rel_l2(torch.cat(a), torch.cat(b)))
+        assert c > (0.9999 if f32 else 0.99), (name, c)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["bf16", "fp8"])
+def test_configs4_architecture_runs_at_full_width(mode):
     """BASELINE configs[4] as SURVEY §8(d) resolves it -- Swin-V2 C=128 (2,2,18,2) heads (4,8,16,32) 384 px window 24,
     pretrained_window_sizes (12,12,12,6), unfrozen + T5-large widths -- binds and steps (no KLAB_ERR_UNSUPPORTED); T5 depth cut to
     2+2 layers to keep the test short.  Properties: finite loss and gradients, repeated forward bit-identical, backward linear."""
@@ -908,7 +1000,7 @@ def test_configs4_architecture_runs_at_full_width():
     t5 = T5Config(d_model=1024, d_ff=4096, num_heads=16, num_layers=2, num_decoder_layers=2)
     args = types.SimpleNamespace(result_dir="/tmp", language_model_name="-", image_model_name="-", image_model_train=True,
                                  transformer_model_name="-")
-    m = MyModel(args, _configs=(sw, t5, t5), _seed=2, dtype="bf16").to("cuda")
+    m = MyModel(args, _configs=(sw, t5, t5), _seed=2, dtype=mode).to("cuda")  # fp8: BASELINE configs[4]'s own mode
     m._direct_grads = True
     m.transformer.eval()
     import bench
@@ -1000,3 +1092,63 @@ def test_fp8_forward_mode_within_twice_the_oracle_cast_error():
     c = cosine(torch.cat(a), torch.cat(b))
     print("fp8 mode: T5 grad cosine", c)
     assert c > 0.98, c
+
+
+@pytest.mark.gpu
+def test_fp8_mode_on_the_configs4_architecture_within_twice_the_oracle_cast_error():
+    """BASELINE configs[4] in ITS OWN mode: dtype="fp8" on the 384 px / window 24 tower (576- and 144-token windows, shifted and
+    unshifted, pretrained_window_sizes (12,12,12,6), C = 128 with heads (4,8,16,32)) + T5-large WIDTHS (d_model 1024, d_ff 4096,
+    16 heads of 64, Le = 144 + 9 = 153: the streaming T5 attention, K = 1024 / 4096 products), depth cut to (2,2,2,2) / 2+2 layers
+    so that the CPU oracle finishes in seconds.  Stated tolerance: |loss - fp32 oracle| <= 2 x the error of the
+    oracle itself with every Linear's operands cast to per-row e4m3 (+ the bf16 allowance 2e-3); gradient cosine >= 0.98 (T5)
+    and >= 0.95 (Swin, whose forward Linears are fp8 too)."""
+    import torch.nn.functional as F
+    from klab_multimodalmodel_amd.engine import SwinConfig, T5Config
+    from klab_multimodalmodel_amd.models.model import MyModel
+    sw = SwinConfig(image_size=384, embed_dim=128, depths=(2, 2, 2, 2), num_heads=(4, 8, 16, 32), window_size=24,
+                    pretrained_window_sizes=(12, 12, 12, 6))
+    t5 = T5Config(d_model=1024, d_kv=64, d_ff=4096, num_heads=16, num_layers=2, num_decoder_layers=2)
+    args = types.SimpleNamespace(result_dir="/tmp", language_model_name="-", image_model_name="-", image_model_train=True,
+                                 transformer_model_name="-")
+    m = MyModel(args, _configs=(sw, t5, t5), _seed=12, dtype="fp8")
+    O, sc, lc, mc, (ssd, lsd, msd) = _oracle_from_model(m)
+    m = m.to("cuda")
+    m.transformer.eval()
+    assert m._engine._cfg.dtype == 2
+    g = torch.Generator().manual_seed(18)
+    B, Ls, Lt = 1, 9, 16
+    pix = torch.randn(B, 3, 384, 384, generator=g)
+    src = torch.randint(2, 32000, (B, Ls), generator=g)
+    tgt = torch.randint(2, 32000, (B, Lt), generator=g)
+    loss = m({"pixel_values": pix.cuda()}, {"input_ids": src.cuda()}, {"input_ids": tgt.cuda()})
+    loss.backward()
+    assert int(m._engine.err_view.item()) == 0
+    msd = {k: v.requires_grad_(True) for k, v in msd.items()}
+    ssd = {k: (v.requires_grad_(True) if v.is_floating_point() else v) for k, v in ssd.items()}
+    torch.set_num_threads(8)
+    ref = O.mymodel_forward(ssd, lsd, msd, sc, lc, mc, pix, src, tgt, training=False, image_model_train=True)
+    ref.backward()
+    real_linear = F.linear
+    try:  # the oracle's own fp8 cast: every F.linear of the path with e4m3 operands
+        O.F.linear = lambda x, w, b=None: _Fp8Linear.apply(x, w, b)
+        with torch.no_grad():
+            cast = O.mymodel_forward({k: v.detach() for k, v in ssd.items()}, lsd, {k: v.detach() for k, v in msd.items()}, sc, lc, mc, pix, src,
+                                     tgt, training=False, image_model_train=True)
+    finally:
+        O.F.linear = real_linear
+    e_cast = abs(float(cast) - float(ref)) / abs(float(ref))
+    e_ours = abs(loss.item() - float(ref)) / abs(float(ref))
+    print("fp8 on configs[4] widths: loss", loss.item(), "oracle", float(ref), "oracle-with-e4m3-cast", float(cast), "rel err ours", e_ours,
+          "cast", e_cast)
+    cos = {}
+    for tree, sd, name in ((m.transformer, msd, "t5"), (m.image_model, ssd, "swin")):
+        a, b = [], []
+        for k, p in tree.named_parameters():
+            if p.grad is None or sd[k].grad is None:
+                continue
+            a.append(p.grad.cpu().flatten())
+            b.append(sd[k].grad.flatten())
+        cos[name] = cosine(torch.cat(a), torch.cat(b))
+        print("fp8 on configs[4] widths:", name, "grad cosine", cos[name], "rel-L2", rel_l2(torch.cat(a), torch.cat(b)))
+    assert e_ours <= 2 * e_cast + 2e-3, (e_ours, e_cast)
+    assert cos["t5"] > 0.98 and cos["swin"] > 0.95, cos

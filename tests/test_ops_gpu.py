@@ -241,7 +241,8 @@ def _attn_ref(q, k, v, bias, causal):
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("B,H,Lq,Lk,dk,causal,use_bias", [(2, 4, 7, 7, 16, True, True), (3, 2, 40, 69, 32, False, False), (3, 2, 20, 20, 32, True, True),
                                                           (2, 8, 58, 58, 64, False, True), (2, 8, 64, 64, 64, True, True),
-                                                          (1, 2, 33, 153, 64, False, False)])
+                                                          (1, 2, 33, 153, 64, False, False), (2, 16, 64, 153, 64, False, False),
+                                                          (1, 2, 153, 153, 64, False, True), (1, 1, 20, 200, 64, False, True)])
 def test_t5_attention_fwd_bwd(ops, dt, B, H, Lq, Lk, dk, causal, use_bias):
     inner = H * dk
     # fused layouts: q in a [B*Lq, 3*inner] buffer, k/v in a [B*Lk, 2*inner] buffer (as the engine uses them)
@@ -269,12 +270,9 @@ def test_t5_attention_fwd_bwd(ops, dt, B, H, Lq, Lk, dk, causal, use_bias):
     dbias = torch.zeros(H, Lq, Lk, device="cuda") if use_bias else None
     # stored-dS + batch-reduction form of the bias gradient (bf16 kernels); B=2 rows of the atomics form stay covered by B=3
     ds_ws = torch.empty(B * H * Lq * ((Lk + 31) // 32 * 32), device="cuda", dtype=dt) if (use_bias and B != 3) else None
-    try:
-        ops.t5_attn_bwd(qd, kview, vview, ctx, lse, dev(dctx), dqb, dkvb[:, :inner], dkvb[:, inner:], dbias=dbias, ds_ws=ds_ws,
-                        ldq=3 * inner, ldk=2 * inner, ldv=2 * inner, lddq=3 * inner, lddk=2 * inner, lddv=2 * inner, **kw)
-    except NotImplementedError:
-        assert dt == torch.float32 and Lk > 128  # round-1 LDS budget of the fp32 parity mode
-        pytest.skip("fp32 backward LDS budget (round-1 single-pass form)")
+    # (fp32 parity mode at Lk > 128, dk = 64 -- T5-large's cross-attention, BASELINE configs[4] -- visits the keys in chunks)
+    ops.t5_attn_bwd(qd, kview, vview, ctx, lse, dev(dctx), dqb, dkvb[:, :inner], dkvb[:, inner:], dbias=dbias, ds_ws=ds_ws,
+                    ldq=3 * inner, ldk=2 * inner, ldv=2 * inner, lddq=3 * inner, lddk=2 * inner, lddv=2 * inner, **kw)
     t = tol(dt) * 2
     assert rel_l2(dqb[:, :inner].float().cpu(), q.grad.transpose(1, 2).reshape(B * Lq, inner)) < t
     assert rel_l2(dkvb[:, :inner].float().cpu(), k.grad.transpose(1, 2).reshape(B * Lk, inner)) < t
@@ -475,7 +473,9 @@ def _swin_attn_ref(qkv, bias, logit_scale, B, R, w, shift, H, C):
 
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("B,R,w,shift,H,C", [(2, 8, 4, 0, 2, 32), (2, 8, 4, 2, 2, 32), (1, 14, 7, 3, 2, 64), (2, 2, 2, 0, 8, 128),
-                                             (2, 14, 7, 0, 1, 32), (2, 28, 7, 3, 3, 96), (3, 8, 4, 2, 2, 64), (2, 7, 7, 0, 4, 128)])
+                                             (2, 14, 7, 0, 1, 32), (2, 28, 7, 3, 3, 96), (3, 8, 4, 2, 2, 64), (2, 7, 7, 0, 4, 128),
+                                             # window 8 = 64 tokens, exactly one tile (the reference's default `window8-256`)
+                                             (1, 16, 8, 4, 2, 64), (2, 8, 8, 0, 1, 32), (1, 16, 8, 0, 4, 128)])
 def test_swin_window_attention_fwd_bwd(ops, dt, B, R, w, shift, H, C):
     n = w * w
     qkv = rnd(B * R * R, 3 * C, seed=1).to(dt)
@@ -518,7 +518,9 @@ def _table_to_dense(btab, index, H, n):
 
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("B,R,w,shift,H,C", [(1, 12, 12, 0, 2, 64), (1, 24, 12, 6, 2, 64), (1, 24, 24, 0, 1, 32), (2, 48, 24, 12, 1, 32),
-                                             (1, 20, 10, 5, 2, 32)])
+                                             (1, 20, 10, 5, 2, 32),
+                                             # window 16 = 256 tokens (`swinv2-base-patch4-window16-256`): shifted, and R == w
+                                             (1, 32, 16, 8, 2, 64), (2, 16, 16, 0, 1, 32)])
 def test_swin_large_window_attention_fwd_bwd(ops, dt, B, R, w, shift, H, C):
     """windows of more than 64 tokens (BASELINE configs[4]: 384 px / window 24 -> n = 576 and 144; HF/swinv2:389-455, 615-618):
     tiled kernels, the position bias looked up in the (2w-1)^2 x H table; checked against the dense-bias reference, in both
@@ -804,11 +806,12 @@ def test_swin_proj_ln_fused_matches_torch(ops, M, Cc):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("R,Cc,Hh,shift", [(14, 64, 2, 0), (14, 64, 2, 3), (14, 128, 4, 3), (7, 128, 4, 0), (14, 256, 8, 3), (14, 256, 8, 0)])
-def test_swin_qkv_attn_fused_matches_two_kernel_path(ops, R, Cc, Hh, shift):
+@pytest.mark.parametrize("R,Cc,Hh,shift,w", [(14, 64, 2, 0, 7), (14, 64, 2, 3, 7), (14, 128, 4, 3, 7), (7, 128, 4, 0, 7), (14, 256, 8, 3, 7),
+                                             (14, 256, 8, 0, 7), (16, 64, 2, 4, 8), (8, 128, 4, 0, 8), (16, 256, 8, 4, 8)])  # window 8: n = 64
+def test_swin_qkv_attn_fused_matches_two_kernel_path(ops, R, Cc, Hh, shift, w):
     """Frozen-tower fusion == klab_gemm (q|k|v projection) followed by klab_swin_attn_fwd on the same inputs (which the oracle
     pins, test_swin_attn_*): the only difference is that q|k|v are not rounded to bf16 before the cosine normalisation."""
-    B, w = 3, 7
+    B = 3
     n = w * w
     g = torch.Generator().manual_seed(9)
     M = B * R * R
