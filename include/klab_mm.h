@@ -60,7 +60,8 @@ typedef struct klab_gemm_args {
   const void* aux; long ldaux; int aux_mode; float aux_scale; /* aux: [M,N] in `dtype` */
   const void* residual; long ldr; int r_dtype;                /* added last */
   float drop_p; const uint32_t* seed_dev; uint32_t drop_tag;  /* dropout before the residual */
-  int name_tag; /* 1: launch under the symbol klab_lmhead_gemm (128x128 NT tile) so profiles can single it out */
+  int name_tag; /* 1: launch under the symbol klab_lmhead_gemm (128x128 NT tile) so profiles can single it out;
+                   2: take the 256x256 eight-wave kernel (mm8p) whenever the shape is legal for it, 3: never (A/B, tests) */
   int atomic_ok; /* with accumulate=1 and a plain f32 product: the kernel may split K and add partial sums with
                     float atomics (summation order, hence the last bits, then vary run to run) */
 } klab_gemm_args;

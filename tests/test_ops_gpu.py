@@ -105,6 +105,73 @@ def test_gemm_wgrad_split_k_atomics(ops, dt, M, N, K):
     assert rel_l2(C2.cpu(), dY.float().t() @ X.float() + 0.5) < tol(dt)
 
 
+# the 256 x 256 eight-wave kernel (csrc/mm8p.hip), forced through name_tag=2: all four operand layouts, ragged M / N edges, an odd
+# number of k-tiles, every epilogue family, C += and the split-K atomic form -- against fp32 torch on the same bf16 operands
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 192), (4896, 1024, 1024), (1000, 520, 320), (300, 264, 4096), (2048, 4096, 1088)])
+@pytest.mark.parametrize("ak,bk", [(True, True), (True, False), (False, False), (False, True)])
+def test_gemm_large_tile_kernel_layouts(ops, M, N, K, ak, bk):
+    dt = torch.bfloat16
+    A = rnd(*((M, K) if ak else (K, M)), seed=11).to(dt)
+    B = rnd(*((N, K) if bk else (K, N)), seed=12).to(dt)
+    ref = (A.float() if ak else A.float().t()) @ (B.float().t() if bk else B.float())
+    C = torch.full((M, N), 7.0, device="cuda")
+    ops.gemm(dev(A), dev(B), C, M=M, N=N, K=K, a_kmajor=ak, b_kmajor=bk, name_tag=2)
+    assert rel_l2(C.cpu(), ref) < 2e-3, rel_l2(C.cpu(), ref)  # (bf16 operands, fp32 accumulation: only the summation order differs)
+    Cb = torch.empty(M, N, device="cuda", dtype=dt)
+    ops.gemm(dev(A), dev(B), Cb, M=M, N=N, K=K, a_kmajor=ak, b_kmajor=bk, name_tag=2)
+    assert rel_l2(Cb.float().cpu(), ref) < 4e-3
+    Cs = torch.empty(M, N, device="cuda", dtype=dt)
+    ops.gemm(dev(A), dev(B), Cs, M=M, N=N, K=K, a_kmajor=ak, b_kmajor=bk, name_tag=3)  # the four-wave ring on the same operands
+    assert rel_l2(Cb.float().cpu(), Cs.float().cpu()) < 4e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 512, 256), (700, 392, 1024)])
+def test_gemm_large_tile_kernel_epilogues(ops, M, N, K):
+    dt = torch.bfloat16
+    A, B = rnd(M, K, seed=1).to(dt), rnd(N, K, seed=2).to(dt)
+    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+    ref = A.float() @ B.float().t()
+    kw = dict(M=M, N=N, K=K, name_tag=2)
+    Ct = torch.empty(M, N, device="cuda", dtype=dt)
+    ops.gemm(dev(A), dev(B), Ct, alpha=0.5, bias=dev(bias), act=1, residual=dev(res), **kw)
+    assert rel_l2(Ct.float().cpu(), F.relu(0.5 * ref + bias) + res) < tol(dt) * 1.5
+    Cf = torch.full((M, N), 1.0, device="cuda")
+    ops.gemm(dev(A), dev(B), Cf, bias=dev(bias), act=2, residual=dev(res.to(dt)), accumulate=True, **kw)
+    assert rel_l2(Cf.cpu(), F.gelu(ref + bias) + res.to(dt).float() + 1.0) < tol(dt) * 1.5
+    Cf2 = torch.empty(M, N, device="cuda")
+    ops.gemm(dev(A), dev(B), Cf2, residual=dev(res), **kw)  # the T5 sub-layer output form: f32 residual stream
+    assert rel_l2(Cf2.cpu(), ref + res) < tol(dt)
+    aux = rnd(M, N, seed=5)
+    aux[aux.abs() < 0.5] = 0
+    aux = aux.to(dt)
+    Ca = torch.empty(M, N, device="cuda", dtype=dt)
+    ops.gemm(dev(A), dev(B), Ca, aux=dev(aux), aux_mode=1, aux_scale=1.25, **kw)  # relu-mask dgrad form
+    assert rel_l2(Ca.float().cpu(), torch.where(aux.float() != 0, ref * 1.25, torch.zeros(()))) < tol(dt)
+    z = aux.float().clone().requires_grad_(True)
+    F.gelu(z).sum().backward()
+    ops.gemm(dev(A), dev(B), Ca, aux=dev(aux), aux_mode=2, **kw)
+    assert rel_l2(Ca.float().cpu(), ref * z.grad) < tol(dt) * 2
+    # dropout: the same mask as the four-wave kernels produce for (seed, tag, element index)
+    sd = seed_word(77)
+    Cd, Cd2 = torch.empty(M, N, device="cuda", dtype=dt), torch.empty(M, N, device="cuda", dtype=dt)
+    ops.gemm(dev(A), dev(B), Cd, act=1, drop_p=0.25, seed=sd, tag=5, **kw)
+    ops.gemm(dev(A), dev(B), Cd2, act=1, drop_p=0.25, seed=sd, tag=5, M=M, N=N, K=K, name_tag=3)
+    assert bool(((Cd == 0) == (Cd2 == 0)).all()) and rel_l2(Cd.float().cpu(), Cd2.float().cpu()) < 4e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 512, 4096), (256, 256, 32128 // 2 // 64 * 64), (1536, 512, 4096)])
+def test_gemm_large_tile_kernel_split_k(ops, M, N, K):
+    dt = torch.bfloat16
+    dY, X = rnd(K, M, seed=7).to(dt), rnd(K, N, seed=8).to(dt)
+    C2 = torch.full((M, N), 0.5, device="cuda")
+    ops.gemm(dev(dY), dev(X), C2, M=M, N=N, K=K, a_kmajor=False, b_kmajor=False, accumulate=True, atomic_ok=True, name_tag=2)
+    assert rel_l2(C2.cpu(), dY.float().t() @ X.float() + 0.5) < 2e-3
+    A, W = rnd(M, K, seed=9).to(dt), rnd(K, N, seed=10).to(dt)  # the LM-head dgrad form: long K-major A, m-major B
+    C3 = torch.zeros(M, N, device="cuda")
+    ops.gemm(dev(A), dev(W), C3, M=M, N=N, K=K, b_kmajor=False, accumulate=True, atomic_ok=True, alpha=0.5, name_tag=2)
+    assert rel_l2(C3.cpu(), 0.5 * (A.float() @ W.float())) < 2e-3
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_lmhead_symbol_matches_generic_gemm(ops, dt):
     M, N, K = 256, 1024, 128
