@@ -112,49 +112,135 @@ __device__ __forceinline__ bf16x8 frag(const char* img, int f, int s, int lane) 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-// copy-out of a [128 x 256] staged slab (rows of the output dtype, 16-B pad per row) as whole 16-byte row pieces
-template <typename OutT>
-__device__ __forceinline__ void copy_out_slab(const GemmP& p, const char* smem, int bm0, int bn0, int tid) {
-  constexpr int ESZ = sizeof(OutT), EPC = 16 / ESZ, CPR = BN / EPC, PITCH = (BN + EPC) * ESZ;
-  char* Cb = reinterpret_cast<char*>(p.C);
-  const bool vec_ok = ((p.ldc * ESZ) & 15) == 0 && (p.N % EPC) == 0;
-  constexpr int NCH = 128 * CPR;
-  if (vec_ok) {
-#pragma unroll 4
-    for (int ch = tid; ch < NCH; ch += NT) {
-      const int row = ch / CPR, cc = ch % CPR;
-      const long m = bm0 + row, n = bn0 + cc * EPC;
-      if (m >= p.M || n >= p.N) continue;
-      f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * PITCH + cc * 16);
-      char* dst = Cb + (m * p.ldc + n) * ESZ;
+// Epilogue of one [128 x 256] slab.  The waves that own the slab park their RAW accumulators (f32) in LDS -- a store per
+// accumulator register, nothing else live -- and then all 512 threads walk the slab as whole row pieces (16 B of output per
+// lane, consecutive lanes on consecutive addresses) and apply the element-wise tail there: alpha, bias, activation, the
+// relu-mask / gelu' operand, dropout, residual, C += -- in klab_gemm's order (gemm_shared.h), with COALESCED reads of the mask
+// and the residual.  (Applying the tail in the MFMA layout, as the four-wave kernels do, kept 128 accumulators live across ten
+// fully unrolled variants: 546 spilled registers and 700 MB of scratch traffic per launch.)
+constexpr int SLAB_PITCH = (BN + 4) * 4;  // bytes per staged f32 row (16-B pad: conflict-free f32x4 stores from the MFMA layout)
+
+// FLAGS: compile-time feature set (EF_* of gemm_shared.h; EF_GENERIC = everything decided at run time).  A body with per-element
+// run-time tests -- ten uniform branches per element -- measured 20 us per 4096 x 4096 output against 10 us for the four-wave
+// kernels' epilogue; each variant here is straight-line code over one 16-byte output vector.
+template <typename OutT, int FLAGS>
+__device__ __forceinline__ void slab_out_v(const GemmP& p, const char* smem, int bm0, int bn0, int tid, float alpha) {
+  constexpr bool GEN = (FLAGS & EF_GENERIC) != 0;
+  constexpr int ESZ = sizeof(OutT), EPT = 16 / ESZ;  // elements per thread per step: one 16-byte output vector
+  constexpr int CPR = BN / EPT, NCH = 128 * CPR;
+  const bool vec_ok = ((p.ldc * ESZ) & 15) == 0 && (p.N % EPT) == 0;
+  const DropCtx dc = make_drop(p.seed, p.tag, p.drop_p);
+  OutT* Cp = reinterpret_cast<OutT*>(p.C);
+  const bf16_t* auxp = reinterpret_cast<const bf16_t*>(p.aux);
+  const bool aux_vec = p.aux && !(p.ldaux & 7) && !((uintptr_t)p.aux & 15);
+  const bool res_vec = p.residual && p.r_f32 && !(p.ldr & 3) && !((uintptr_t)p.residual & 15);
+#pragma unroll 2
+  for (int ch = tid; ch < NCH; ch += NT) {
+    const int row = ch / CPR, cc = ch % CPR;
+    const long m = bm0 + row;
+    const int n0 = bn0 + cc * EPT;
+    if (m >= p.M || n0 >= p.N) continue;
+    float x[EPT];
+#pragma unroll
+    for (int q = 0; q < EPT / 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * SLAB_PITCH + (cc * EPT + q * 4) * 4);
+      x[q * 4 + 0] = v[0]; x[q * 4 + 1] = v[1]; x[q * 4 + 2] = v[2]; x[q * 4 + 3] = v[3];
+    }
+    const int nv = (p.N - n0) < EPT ? (p.N - n0) : EPT;  // valid elements (ragged last vector)
+    const bool whole = vec_ok && nv == EPT;
+    // operands of the tail as whole vectors where alignment allows (interior vectors of aligned tensors: the common case)
+    float av[EPT], rv[EPT];
+    constexpr bool NEED_AUX = GEN || (FLAGS & (EF_AUXNZ | EF_DGELU)) != 0, NEED_RES = GEN || (FLAGS & EF_RES) != 0;
+    if constexpr (NEED_AUX) {
+      if (p.aux) {
+        if (whole && aux_vec && EPT == 8) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(auxp + m * p.ldaux + n0);
+#pragma unroll
+          for (int u = 0; u < EPT; ++u) av[u] = (float)a[u & 7];
+        } else {
+#pragma unroll
+          for (int u = 0; u < EPT; ++u) av[u] = (float)auxp[m * p.ldaux + n0 + (u < nv ? u : 0)];
+        }
+      }
+    }
+    if constexpr (NEED_RES) {
+      if (p.residual) {
+        if (whole && res_vec) {
+#pragma unroll
+          for (int q = 0; q < EPT / 4; ++q) {
+            const f32x4 r = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.residual) + m * p.ldr + n0 + q * 4);
+            rv[q * 4 + 0] = r[0]; rv[q * 4 + 1] = r[1]; rv[q * 4 + 2] = r[2]; rv[q * 4 + 3] = r[3];
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < EPT; ++u) {
+            const long n = n0 + (u < nv ? u : 0);
+            rv[u] = p.r_f32 ? reinterpret_cast<const float*>(p.residual)[m * p.ldr + n] : (float)reinterpret_cast<const bf16_t*>(p.residual)[m * p.ldr + n];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+      const int n = n0 + (u < nv ? u : 0);  // clamped: the value of an invalid element is never stored
+      float y = x[u] * alpha;
+      if constexpr (GEN) {
+        if (p.bias) y += p.bias[n];
+        if (p.act == KLAB_ACT_RELU) y = fmaxf(y, 0.f);
+        else if (p.act == KLAB_ACT_GELU) y = gelu_for<bf16_t>(y);
+        if (p.aux) {
+          if (p.aux_mode == KLAB_AUX_NONZERO) y = (av[u] != 0.f) ? y * p.aux_scale : 0.f;
+          else if (p.aux_mode == KLAB_AUX_DGELU) y *= gelu_erf_grad(av[u]);
+        }
+        y *= drop_mult(dc, (uint64_t)m * (uint64_t)p.N + (uint64_t)n);
+        if (p.residual) y += rv[u];
+      } else {
+        if constexpr (FLAGS & EF_BIAS) y += p.bias[n];
+        if constexpr (FLAGS & EF_RELU) y = fmaxf(y, 0.f);
+        if constexpr (FLAGS & EF_GELU) y = gelu_for<bf16_t>(y);
+        if constexpr (FLAGS & EF_AUXNZ) y = (av[u] != 0.f) ? y * p.aux_scale : 0.f;
+        if constexpr (FLAGS & EF_DGELU) y *= gelu_erf_grad(av[u]);
+        if constexpr (FLAGS & EF_DROP) y *= drop_mult32_nb(dc, (uint32_t)m * (uint32_t)p.N + (uint32_t)n);  // (M * N < 2^32: fill_gemmp)
+        if constexpr (FLAGS & EF_RES) y += rv[u];
+      }
+      x[u] = y;
+    }
+    OutT* dst = Cp + m * p.ldc + n0;
+    if (whole) {
       if (p.accumulate) {
         if constexpr (ESZ == 4) {
           const f32x4 o = *reinterpret_cast<const f32x4*>(dst);
-          v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+          x[0] += o[0]; x[1] += o[1]; x[2] += o[2]; x[3] += o[3];
         } else {
-          bf16x8 nv = __builtin_bit_cast(bf16x8, v);
           const bf16x8 o = *reinterpret_cast<const bf16x8*>(dst);
 #pragma unroll
-          for (int u = 0; u < 8; ++u) nv[u] = (bf16_t)((float)nv[u] + (float)o[u]);
-          v = __builtin_bit_cast(f32x4, nv);
+          for (int u = 0; u < EPT; ++u) x[u] += (float)o[u & 7];
         }
       }
-      *reinterpret_cast<f32x4*>(dst) = v;
-    }
-  } else {
-    for (int ch = tid; ch < NCH; ch += NT) {
-      const int row = ch / CPR, cc = ch % CPR;
-      const long m = bm0 + row;
-      if (m >= p.M) continue;
-      for (int u = 0; u < EPC; ++u) {
-        const long n = bn0 + cc * EPC + u;
-        if (n >= p.N) break;
-        const OutT x = *reinterpret_cast<const OutT*>(smem + row * PITCH + (cc * EPC + u) * ESZ);
-        OutT* d = reinterpret_cast<OutT*>(Cb) + m * p.ldc + n;
-        *d = p.accumulate ? from_f32<OutT>(to_f32(x) + to_f32(*d)) : x;
-      }
+      if constexpr (ESZ == 4) *reinterpret_cast<f32x4*>(dst) = f32x4{x[0], x[1], x[2], x[3]};
+      else *reinterpret_cast<bf16x8*>(dst) = bf16x8{(bf16_t)x[0], (bf16_t)x[1], (bf16_t)x[2], (bf16_t)x[3], (bf16_t)x[4 % EPT], (bf16_t)x[5 % EPT], (bf16_t)x[6 % EPT], (bf16_t)x[7 % EPT]};
+    } else {
+      for (int u = 0; u < nv; ++u) dst[u] = from_f32<OutT>(p.accumulate ? x[u] + to_f32(dst[u]) : x[u]);
     }
   }
+}
+
+template <typename OutT>
+__device__ __forceinline__ void slab_out(const GemmP& p, const char* smem, int bm0, int bn0, int tid, float alpha) {
+#define KLAB_SO(F) slab_out_v<OutT, F>(p, smem, bm0, bn0, tid, alpha)
+  switch (p.epi) {  // workgroup-uniform: only the selected variant's instructions are fetched
+    case 0: KLAB_SO(0); break;
+    case EF_BIAS: KLAB_SO(EF_BIAS); break;
+    case EF_BIAS | EF_GELU: KLAB_SO(EF_BIAS | EF_GELU); break;
+    case EF_RELU: KLAB_SO(EF_RELU); break;
+    case EF_RELU | EF_DROP: KLAB_SO(EF_RELU | EF_DROP); break;
+    case EF_RES: KLAB_SO(EF_RES); break;
+    case EF_DROP | EF_RES: KLAB_SO(EF_DROP | EF_RES); break;
+    case EF_AUXNZ: KLAB_SO(EF_AUXNZ); break;
+    case EF_DGELU: KLAB_SO(EF_DGELU); break;
+    default: KLAB_SO(EF_GENERIC); break;
+  }
+#undef KLAB_SO
 }
 
 template <bool AK, bool BKM, bool ATOMIC>
@@ -341,29 +427,20 @@ __global__ __launch_bounds__(512) void mm8p_kernel(GemmP p) {
         }
       }
   } else {
-    // two slabs of 128 rows (the two wave rows), each staged in LDS in the output dtype and streamed out as whole rows
+    // two slabs of 128 rows (the two wave rows)
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
       __syncthreads();  // ring reads / the previous slab's copy-out are done
       if ((wave >> 2) == half) {
-#define KLAB_EPI(F) staged_epilogue_v<bf16_t, 128, BN, 8, 4, F>(p, acc, alpha, smem, bm0 + half * 128, bn0, 0, wn, tid, lane)
-        switch (p.epi) {
-          case 0: KLAB_EPI(0); break;
-          case EF_BIAS: KLAB_EPI(EF_BIAS); break;
-          case EF_BIAS | EF_GELU: KLAB_EPI(EF_BIAS | EF_GELU); break;
-          case EF_RELU: KLAB_EPI(EF_RELU); break;
-          case EF_RELU | EF_DROP: KLAB_EPI(EF_RELU | EF_DROP); break;
-          case EF_RES: KLAB_EPI(EF_RES); break;
-          case EF_DROP | EF_RES: KLAB_EPI(EF_DROP | EF_RES); break;
-          case EF_AUXNZ: KLAB_EPI(EF_AUXNZ); break;
-          case EF_DGELU: KLAB_EPI(EF_DGELU); break;
-          default: KLAB_EPI(EF_GENERIC); break;
-        }
-#undef KLAB_EPI
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<f32x4*>(smem + (i * 16 + (lane & 15)) * SLAB_PITCH + (wn + j * 16 + (lane >> 4) * 4) * 4) = acc[i][j];
       }
       __syncthreads();
-      if (p.c_f32) copy_out_slab<float>(p, smem, bm0 + half * 128, bn0, tid);
-      else copy_out_slab<bf16_t>(p, smem, bm0 + half * 128, bn0, tid);
+      if (p.c_f32) slab_out<float>(p, smem, bm0 + half * 128, bn0, tid, alpha);
+      else slab_out<bf16_t>(p, smem, bm0 + half * 128, bn0, tid, alpha);
     }
   }
 }
@@ -389,10 +466,20 @@ int mm8p_try(const GemmP& pin, bool atomic_ok, int force, hipStream_t s) {
     while (tiles * splits * 2 <= ncu && nt / (splits * 2) >= 8) splits *= 2;
   }
   if (mode == 1 && force <= 0) {
-    // heuristic: long K, and enough 256 x 256 tiles (x splits) to occupy at least ~60 % of the CUs -- or few tiles on purpose
-    // for products that run beside a main chain (weight gradients): the caller asks for those through KLAB_GEMM_P8=2 paths
-    if (p.K < 1024) return KLAB_ERR_UNSUPPORTED;
-    if (tiles * splits < 150) return KLAB_ERR_UNSUPPORTED;
+    // Measured envelope (tools/gemm_bench.py --sq, KLAB_BENCH_AB=1): per 64 k the main loop takes 1.5 us on a 4096 x 4096 output
+    // (1.44 PFLOP/s marginal) against 1.7 -> 4.0 us for the four-wave ring as K grows from 1024 to 8192, but a launch carries a
+    // larger fixed cost (one workgroup per CU: nothing hides the ring fill and the two-slab epilogue).  It pays from K = 2048 per
+    // split, and only when the 256 x 256 tiles (x splits) fill the chip's 256 CUs in whole rounds.
+    // Same-process A/B per shape (profiles/r03_gemm_large_tile_ab.txt): wins from K = 1024 per split when the workgroups fill
+    // whole rounds of the chip (4096 x 4096: 856 vs 762 TFLOP/s at K = 1024, 1247 vs 725 at K = 4096), loses when they do not
+    // (T5-large M = 4896, N = 1024: 80 tiles on 256 CUs) and on long-thin outputs whose one operand every tile re-reads (the
+    // LM-head weight gradient, 126 x 2 tiles).
+    const long wgs = tiles * splits;
+    const long rounds = (wgs + ncu - 1) / ncu;
+    const long tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    if (p.K / splits < 1024) return KLAB_ERR_UNSUPPORTED;
+    if (wgs * 100 < rounds * ncu * (p.K / splits >= 2048 ? 80 : 90)) return KLAB_ERR_UNSUPPORTED;
+    if (splits == 1 && (tiles_m < 4 || tiles_n < 4)) return KLAB_ERR_UNSUPPORTED;
   }
   p.splits = splits;
   // the copy-out variants of the small-tile kernels do not exist here: fold them back into the accumulator-layout forms

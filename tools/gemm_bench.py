@@ -99,6 +99,9 @@ def main():
         shapes, flt = LARGE, flt[1:]
     elif flt and flt[0] == "--cfg3":
         shapes, flt = CFG3, flt[1:]
+    elif flt and flt[0] == "--sq":  # 4096 x 4096 outputs (256 tiles of 256 x 256) over K: per-k-tile slope and fixed cost of a kernel
+        shapes, flt = [(f"sq k{K} {n}", 4096, 4096, K, ak, bk, False) for ak, bk, n in ((True, True, "tt"), (True, False, "tf"), (False, False, "ff"))
+                       for K in (128, 512, 1024, 2048, 4096, 8192)], flt[1:]
     elif flt and flt[0] == "--ksweep":  # fixed cost of a launch: the same output tile grid at K = 64 ... 4096
         shapes, flt = [(f"k{K} {n}", 4096, N, K, True, bk, False) for N in (512, 2048) for bk, n in ((True, f"N{N} fwd"), (False, f"N{N} dgrad"))
                        for K in (64, 128, 256, 512, 1024, 2048, 4096)], flt[1:]
