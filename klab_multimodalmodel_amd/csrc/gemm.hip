@@ -159,160 +159,6 @@ __device__ __forceinline__ bf16x8 load_frag_bf16(const char* tile, int r0, int k
 }
 
 
-template <typename T, int BM, int BN, int CO = 0, int NT = 256>
-__device__ __forceinline__ void copy_out_tile(const GemmP& p, const char* smem, int bm0, int bn0, int tid) {
-  const bool f32out = p.c_f32 || sizeof(T) == 4;
-  const int pitchB = f32out ? (BN + 4) * 4 : (BN + 8) * 2;
-  const int esz = f32out ? 4 : 2;
-  const int sh = f32out ? 2 : 3;            // log2(elements per 16-B chunk)
-  const int cpr_sh = (BN == 128 ? 7 : 6) - sh;  // log2(chunks per tile row)
-  const bool vec_ok = ((p.ldc * esz) & 15) == 0 && (p.N & ((1 << sh) - 1)) == 0;
-  char* Cb = reinterpret_cast<char*>(p.C);
-  const int nch = BM << cpr_sh;
-  // Interior tiles (the common case) with whole 16-byte rows: every chunk of the thread is read from LDS -- and its residual /
-  // mask operand requested from memory -- BEFORE the first store.  The general loop below does read, (load,) store per chunk; on
-  // this ISA a store counts in vmcnt like a load, so each chunk's operand wait also drained the stores issued before it: 8-16
-  // memory round trips in a row at the end of every tile.
-  if (bm0 + BM <= p.M && bn0 + BN <= p.N && vec_ok && (!p.accumulate || (f32out && CO == 0)) && !(p.ablate & 64)) {
-    auto fast = [&](auto esz_c) {
-      constexpr int ESZ = decltype(esz_c)::value, EPC = 16 / ESZ, CPR = BN / EPC, PER = BM * CPR / NT;
-      static_assert(BM * CPR % NT == 0, "whole chunks per thread");
-      f32x4 val[PER], opnd[PER];
-#pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        const int ch = tid + i * NT, row = ch / CPR, cc = ch % CPR;
-        val[i] = *reinterpret_cast<const f32x4*>(smem + row * ((BN + 16 / ESZ) * ESZ) + cc * 16);
-        const long m = bm0 + row, n = bn0 + cc * EPC;
-        if constexpr (CO == 0 && ESZ == 4) { if (p.accumulate) opnd[i] = *reinterpret_cast<const f32x4*>(Cb + (m * p.ldc + n) * ESZ); }  // C += tile
-        if constexpr ((CO & EF_RES_CO) != 0) opnd[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.residual) + m * p.ldr + n);
-        if constexpr ((CO & (EF_AUXNZ_CO | EF_DGELU_CO)) != 0) opnd[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const bf16_t*>(p.aux) + m * p.ldaux + n);
-      }
-#pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        const int ch = tid + i * NT, row = ch / CPR, cc = ch % CPR;
-        const long m = bm0 + row, n = bn0 + cc * EPC;
-        f32x4 v = val[i];
-        if constexpr (CO == 0 && ESZ == 4) { if (p.accumulate) { v[0] += opnd[i][0]; v[1] += opnd[i][1]; v[2] += opnd[i][2]; v[3] += opnd[i][3]; } }
-        if constexpr ((CO & EF_RES_CO) != 0) { v[0] += opnd[i][0]; v[1] += opnd[i][1]; v[2] += opnd[i][2]; v[3] += opnd[i][3]; }
-        if constexpr ((CO & EF_AUXNZ_CO) != 0) {
-          bf16x8 nv = __builtin_bit_cast(bf16x8, v);
-          const bf16x8 a = __builtin_bit_cast(bf16x8, opnd[i]);
-#pragma unroll
-          for (int u = 0; u < 8; ++u) nv[u] = ((float)a[u] != 0.f) ? nv[u] : (bf16_t)0.f;
-          v = __builtin_bit_cast(f32x4, nv);
-        }
-        if constexpr ((CO & EF_DGELU_CO) != 0) {
-          bf16x8 nv = __builtin_bit_cast(bf16x8, v);
-          const bf16x8 a = __builtin_bit_cast(bf16x8, opnd[i]);
-#pragma unroll
-          for (int u = 0; u < 8; ++u) nv[u] = (bf16_t)((float)nv[u] * gelu_erf_grad((float)a[u]));
-          v = __builtin_bit_cast(f32x4, nv);
-        }
-        *reinterpret_cast<f32x4*>(Cb + (m * p.ldc + n) * ESZ) = v;
-      }
-    };
-    if (f32out) fast(std::integral_constant<int, 4>{});
-    else fast(std::integral_constant<int, 2>{});
-    return;
-  }
-  for (int ch = tid; ch < nch; ch += NT) {
-    const int row = ch >> cpr_sh, cc = ch & ((1 << cpr_sh) - 1);
-    const int m = bm0 + row, n = bn0 + (cc << sh);
-    if (m >= p.M || n >= p.N) continue;
-    const char* src = smem + row * pitchB + cc * 16;
-    char* dst = Cb + ((long)m * p.ldc + n) * esz;
-    if constexpr (CO & EF_AUXNZ_CO) {  // bf16 tile, bf16 mask source, vector path guaranteed by the host
-      bf16x8 nv = *reinterpret_cast<const bf16x8*>(src);
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.aux) + (long)m * p.ldaux + n);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) nv[u] = ((float)a[u] != 0.f) ? nv[u] : (bf16_t)0.f;
-      *reinterpret_cast<bf16x8*>(dst) = nv;
-      continue;
-    }
-    if constexpr (CO & EF_DGELU_CO) {  // bf16 tile, bf16 pre-activation, vector path guaranteed by the host
-      bf16x8 nv = *reinterpret_cast<const bf16x8*>(src);
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.aux) + (long)m * p.ldaux + n);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) nv[u] = (bf16_t)((float)nv[u] * gelu_erf_grad((float)a[u]));
-      *reinterpret_cast<bf16x8*>(dst) = nv;
-      continue;
-    }
-    if constexpr (CO & EF_RES_CO) {    // f32 tile + f32 residual, vector path guaranteed by the host
-      f32x4 val = *reinterpret_cast<const f32x4*>(src);
-      const f32x4 r = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.residual) + (long)m * p.ldr + n);
-      val[0] += r[0]; val[1] += r[1]; val[2] += r[2]; val[3] += r[3];
-      *reinterpret_cast<f32x4*>(dst) = val;
-      continue;
-    }
-    if (vec_ok) {
-      f32x4 val = *reinterpret_cast<const f32x4*>(src);
-      if (p.accumulate) {
-        if (f32out) {
-          const f32x4 old = *reinterpret_cast<const f32x4*>(dst);
-          val[0] += old[0]; val[1] += old[1]; val[2] += old[2]; val[3] += old[3];
-        } else {
-          bf16x8 nv = *reinterpret_cast<const bf16x8*>(src);
-          const bf16x8 old = *reinterpret_cast<const bf16x8*>(dst);
-#pragma unroll
-          for (int u = 0; u < 8; ++u) nv[u] = (bf16_t)((float)nv[u] + (float)old[u]);
-          *reinterpret_cast<bf16x8*>(dst) = nv;
-          continue;
-        }
-      }
-      if (p.ablate & 64) {  // experiment: write-through (sc1) stores -- nothing left dirty in L2 for the end-of-kernel release
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(val) : "memory");
-      } else {
-        *reinterpret_cast<f32x4*>(dst) = val;
-      }
-    } else {
-      const int epc = 1 << sh;
-      const int nv = (p.N - n) < epc ? (p.N - n) : epc;
-      for (int u = 0; u < nv; ++u) {
-        if (f32out) {
-          float x = reinterpret_cast<const float*>(src)[u];
-          float* d = reinterpret_cast<float*>(dst) + u;
-          *d = p.accumulate ? x + *d : x;
-        } else {
-          float x = (float)reinterpret_cast<const bf16_t*>(src)[u];
-          bf16_t* d = reinterpret_cast<bf16_t*>(dst) + u;
-          *d = (bf16_t)(p.accumulate ? x + (float)*d : x);
-        }
-      }
-    }
-  }
-}
-
-template <typename T, int BM, int BN, int MI, int NI, int NT = 256>
-__device__ __forceinline__ void staged_epilogue(const GemmP& p, f32x4 (&acc)[MI][NI], float alpha, char* smem, int bm0, int bn0, int wm,
-                                                int wn, int tid, int lane) {
-#define KLAB_EPI(F) staged_epilogue_v<T, BM, BN, MI, NI, F>(p, acc, alpha, smem, bm0, bn0, wm, wn, tid, lane)
-  switch (p.epi) {  // wave-uniform: only the selected variant's instructions are ever fetched
-    case 0: KLAB_EPI(0); break;
-    case EF_BIAS: KLAB_EPI(EF_BIAS); break;
-    case EF_BIAS | EF_GELU: KLAB_EPI(EF_BIAS | EF_GELU); break;
-    case EF_RELU: KLAB_EPI(EF_RELU); break;
-    case EF_RELU | EF_DROP: KLAB_EPI(EF_RELU | EF_DROP); break;
-    case EF_RES: KLAB_EPI(EF_RES); break;
-    case EF_DROP | EF_RES: KLAB_EPI(EF_DROP | EF_RES); break;
-    case EF_AUXNZ: KLAB_EPI(EF_AUXNZ); break;
-    case EF_DGELU: KLAB_EPI(EF_DGELU); break;
-    case EF_AUXNZ_CO: KLAB_EPI(EF_AUXNZ_CO); break;
-    case EF_DGELU_CO: KLAB_EPI(0); break;
-    case EF_RES_CO: KLAB_EPI(0); break;
-    case EF_DROP | EF_RES_CO: KLAB_EPI(EF_DROP); break;
-    default: KLAB_EPI(EF_GENERIC); break;
-  }
-#undef KLAB_EPI
-  __syncthreads();
-  if (p.ablate & 8) return;
-  if constexpr (sizeof(T) == 2) {
-    if (p.epi == EF_AUXNZ_CO) { copy_out_tile<T, BM, BN, EF_AUXNZ_CO, NT>(p, smem, bm0, bn0, tid); return; }
-    if (p.epi == EF_DGELU_CO) { copy_out_tile<T, BM, BN, EF_DGELU_CO, NT>(p, smem, bm0, bn0, tid); return; }
-  }
-  if (p.epi == EF_RES_CO || p.epi == (EF_DROP | EF_RES_CO)) { copy_out_tile<T, BM, BN, EF_RES_CO, NT>(p, smem, bm0, bn0, tid); return; }
-  copy_out_tile<T, BM, BN, 0, NT>(p, smem, bm0, bn0, tid);
-}
-template <int BM, int BN> constexpr int epilogue_lds_bytes(bool f32out) { return f32out ? BM * (BN + 4) * 4 : BM * (BN + 8) * 2; }
 
 // ---- bf16 fast path: asynchronous global->LDS ring (all four operand layouts) -------------------------
 // The register-staged loop further down exposes one full memory latency (~1 us under load) per k-tile; here
@@ -1016,6 +862,7 @@ static int dispatch_layout(const GemmP& p, bool atomic, hipStream_t s) {
 // tile / split-K choice: the largest tile that still gives about one workgroup per CU; when even the
 // smallest does not and the caller allows atomic accumulation, split K until the chip is covered.
 int mm8p_try(const GemmP& pin, bool atomic_ok, int force, hipStream_t s);  // mm8p.hip: 256 x 256 tiles, eight waves, BK = 64
+int mmf8_try(const GemmP& pin, const float* sa, const float* sb, long sb_stride, int force, hipStream_t s);  // mmf8.hip: block-scaled fp8 MFMA
 
 template <typename T>
 static int dispatch_tile(GemmP& p, bool atomic_ok, hipStream_t s, int p8_force = 0) {
@@ -1646,6 +1493,10 @@ extern "C" int klab_gemm_fp8(const klab_gemm_args* a, const float* a_row_scale, 
   fill_gemmp(a, p);
   Fp8Scales sc{a_row_scale, b_row_scale, b_scale_stride};
   hipStream_t s = (hipStream_t)stream;
+  {  // the block-scaled instruction (2x the bf16 MFMA rate), opt-in (measured slower on this path's shapes: see mmf8.hip)
+    const int rc = mmf8_try(p, a_row_scale, b_row_scale, b_scale_stride, a->name_tag == 2 ? 1 : (a->name_tag == 3 ? -1 : 0), s);
+    if (rc != KLAB_ERR_UNSUPPORTED) return rc;
+  }
   auto tiles = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
   // LDS-DMA ring form (whole 64-byte k-tiles, rows the DMA can address): the production path; the register-staged kernels below
   // take what is left (K % 64 != 0, tiny operands) and remain reachable with KLAB_FP8_GLDS=0

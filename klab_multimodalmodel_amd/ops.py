@@ -52,13 +52,14 @@ def quant_fp8_rows(x):
     return x8, sc
 
 
-def gemm_fp8(A8, sa, B8, sb, C_out, *, alpha=1.0, bias=None, act=L.ACT_NONE, residual=None, drop_p=0.0, seed=None, tag=0):
+def gemm_fp8(A8, sa, B8, sb, C_out, *, alpha=1.0, bias=None, act=L.ACT_NONE, residual=None, drop_p=0.0, seed=None, tag=0, name_tag=0):
     """C[M,N] = epilogue(alpha * sa[m] sb[n] * A8 @ B8^T): A8 [M,K], B8 [N,K] e4m3 bytes (uint8), per-row scales"""
     lib = L.load()
     a = L.GemmArgs()
     a.M, a.K = A8.shape
     a.N = B8.shape[0]
     a.dtype = L.BF16
+    a.name_tag = name_tag  # 2: the block-scaled kernel (mmf8.hip) when K % 128 == 0, 3: never
     a.A, a.lda, a.a_kmajor = A8.data_ptr(), A8.stride(0), 1
     a.B, a.ldb, a.b_kmajor = B8.data_ptr(), B8.stride(0), 1
     a.C, a.ldc, a.c_dtype = C_out.data_ptr(), C_out.stride(0), L.dtype_code(C_out.dtype)

@@ -467,6 +467,14 @@ def test_fp8_gemm_matches_emulated_quantisation(ops, M, N, K):
     assert rel_l2(c32.cpu(), ref + res) < 2e-4
     # against the unquantised product: the e4m3 round-off itself (2^-4 relative per element, averaged over K)
     assert rel_l2(ref, a.float() @ b.float().t()) < 6e-2
+    if K % 128 == 0:  # the block-scaled instruction (csrc/mmf8.hip, v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales): same numbers
+        for out_dt in (torch.bfloat16, torch.float32):
+            c = torch.empty(M, N, device="cuda", dtype=out_dt)
+            ops.gemm_fp8(a8, sa_k, b8, sb_k, c, name_tag=2)
+            assert rel_l2(c.float().cpu(), ref) < (4e-3 if out_dt == torch.bfloat16 else 2e-4)
+        c = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        ops.gemm_fp8(a8, sa_k, b8, sb_k, c, alpha=0.5, bias=dev(bias), act=ops.L.ACT_RELU, name_tag=2)
+        assert rel_l2(c.float().cpu(), torch.relu(0.5 * ref + bias)) < 4e-3
 
 
 @pytest.mark.parametrize("rows,d", [(300, 512), (77, 1024), (4096, 768), (5, 256), (1000, 64)])
