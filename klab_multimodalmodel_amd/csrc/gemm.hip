@@ -862,7 +862,8 @@ static int dispatch_layout(const GemmP& p, bool atomic, hipStream_t s) {
 // tile / split-K choice: the largest tile that still gives about one workgroup per CU; when even the
 // smallest does not and the caller allows atomic accumulation, split K until the chip is covered.
 int mm8p_try(const GemmP& pin, bool atomic_ok, int force, hipStream_t s);  // mm8p.hip: 256 x 256 tiles, eight waves, BK = 64
-int mmf8_try(const GemmP& pin, const float* sa, const float* sb, long sb_stride, int force, hipStream_t s);  // mmf8.hip: block-scaled fp8 MFMA
+int mmf8_try(const GemmP& pin, const float* sa, const float* sb, long sb_stride, int force, hipStream_t s);
+int mm8p_grouped_try(const klab_gemm_args* list, int n, hipStream_t s);  // mm8p.hip: a layer's weight gradients on 256 x 256 tiles  // mmf8.hip: block-scaled fp8 MFMA
 
 template <typename T>
 static int dispatch_tile(GemmP& p, bool atomic_ok, hipStream_t s, int p8_force = 0) {
@@ -1324,6 +1325,10 @@ extern "C" int klab_gemm_grouped(const klab_gemm_args* list, int n, void* stream
   using namespace klab;
   if (!list || n < 0) return KLAB_ERR_BADARG;
   static const bool grouped_on = [] { const char* e = getenv("KLAB_GEMM_GROUPED"); return !e || atoi(e) != 0; }();
+  {  // (experiment, KLAB_WGRAD_P8=1) the whole list on 256 x 256 tiles without split-K: mm8p.hip
+    const int rc = mm8p_grouped_try(list, n, (hipStream_t)stream);
+    if (rc != KLAB_ERR_UNSUPPORTED) return rc;
+  }
   GroupP g;
   g.n = 0;
   int blocks = 0;

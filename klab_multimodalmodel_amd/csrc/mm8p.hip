@@ -244,13 +244,12 @@ __device__ __forceinline__ void slab_out(const GemmP& p, const char* smem, int b
 }
 
 template <bool AK, bool BKM, bool ATOMIC>
-__global__ __launch_bounds__(512) void mm8p_kernel(GemmP p) {
+__device__ __forceinline__ void mm8p_body(const GemmP& p, const int bid) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;  // 2 x 4 waves
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  const int bid = blockIdx.x;
   const int tile = bid % tiles, split = bid / tiles;
   int bm0, bn0;
   tile_of_block(p, BM, BN, tile, bm0, bn0);
@@ -445,7 +444,65 @@ __global__ __launch_bounds__(512) void mm8p_kernel(GemmP p) {
   }
 }
 
+template <bool AK, bool BKM, bool ATOMIC>
+__global__ __launch_bounds__(512) void mm8p_kernel(GemmP p) { mm8p_body<AK, BKM, ATOMIC>(p, blockIdx.x); }
+
+// Up to 8 weight-gradient products dW[N_out, K_in] = dY^T X (both operands token-major, f32 C += product) in ONE grid: the
+// weight gradients of a T5 layer (HF/t5 autograd of :83-94, 206-209).  One 256 x 256 tile over the WHOLE contraction per
+// workgroup: no split-K, no atomics, half the operand traffic of the 128 x 128 split-K form (gemm.hip's grouped kernel), and a
+// layer's gradients occupy ~50 CUs instead of all 256 -- they run on a side stream beside the activation-gradient chain.
+struct Group8Entry { const void* A; long lda; const void* B; long ldb; float* C; long ldc; int M, N, K, start; float alpha; };
+struct Group8P { Group8Entry e[8]; int n; };
+__global__ __launch_bounds__(512) void mm8p_grouped_tn_kernel(Group8P g) {
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < 8; ++k)
+    if (k < g.n && (int)blockIdx.x >= g.e[k].start) i = k;
+  const Group8Entry& e = g.e[i];
+  GemmP p;
+  p.M = e.M; p.N = e.N; p.K = e.K;
+  p.A = e.A; p.lda = e.lda; p.a_kmajor = 0;
+  p.B = e.B; p.ldb = e.ldb; p.b_kmajor = 0;
+  p.C = e.C; p.ldc = e.ldc; p.c_f32 = 1; p.accumulate = 1;
+  p.alpha = e.alpha; p.alpha_dev = nullptr; p.bias = nullptr; p.act = 0;
+  p.aux = nullptr; p.ldaux = 0; p.aux_mode = 0; p.aux_scale = 1.f;
+  p.residual = nullptr; p.ldr = 0; p.r_f32 = 1;
+  p.drop_p = 0.f; p.seed = nullptr; p.tag = 0;
+  p.splits = 1; p.epi = 0; p.ablate = 0;
+  mm8p_body<false, false, false>(p, (int)blockIdx.x - e.start);
+}
+
 }  // namespace p8
+
+// grouped weight gradients on the large tiles: returns KLAB_ERR_UNSUPPORTED unless EVERY member fits (the caller then uses the
+// 128 x 128 split-K grouped kernel for the whole list)
+int mm8p_grouped_try(const klab_gemm_args* list, int n, hipStream_t s) {
+  using namespace p8;
+  static const int mode = [] { const char* e = getenv("KLAB_WGRAD_P8"); return e ? atoi(e) : 0; }();  // 0: off (default), 1: on
+  if (mode == 0 || n <= 0 || n > 8) return KLAB_ERR_UNSUPPORTED;
+  Group8P g;
+  g.n = 0;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const klab_gemm_args* a = &list[i];
+    const bool ok = a->dtype == KLAB_BF16 && !a->a_kmajor && !a->b_kmajor && a->c_dtype == KLAB_F32 && a->accumulate && !a->bias && !a->act &&
+                    !a->aux && !a->residual && a->drop_p == 0.f && !a->alpha_dev && a->M >= 128 && a->N >= 128 && (a->K % BK) == 0 &&
+                    a->K >= 1024 && !(a->M & 7) && !(a->N & 7) && !(a->lda & 7) && !(a->ldb & 7) && !(a->ldc & 3) &&
+                    !((uintptr_t)a->A & 15) && !((uintptr_t)a->B & 15) && !((uintptr_t)a->C & 15);
+    if (!ok) return KLAB_ERR_UNSUPPORTED;
+    Group8Entry& e = g.e[g.n++];
+    e.A = a->A; e.lda = a->lda; e.B = a->B; e.ldb = a->ldb; e.C = (float*)a->C; e.ldc = a->ldc;
+    e.M = a->M; e.N = a->N; e.K = a->K; e.start = blocks; e.alpha = a->alpha;
+    blocks += ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
+  }
+  const size_t epi_bytes = (size_t)128 * SLAB_PITCH;
+  const size_t lds = LDS_RING > epi_bytes ? LDS_RING : epi_bytes;
+  int rc = ensure_dyn_lds(reinterpret_cast<const void*>(mm8p_grouped_tn_kernel), lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(mm8p_grouped_tn_kernel, dim3((unsigned)blocks), dim3(NT), lds, s, g);
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
 
 // Host side: is this product worth the large tiles, and the launch.  Returns KLAB_ERR_UNSUPPORTED when it is not taken.
 int mm8p_try(const GemmP& pin, bool atomic_ok, int force, hipStream_t s) {

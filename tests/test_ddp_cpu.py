@@ -46,6 +46,19 @@ def _worker(rank, world, port, q):
         ok = ok and torch.allclose(f2["main"], base * (sum(range(1, world + 1)) / world)) and red.world_active()
         red.finish_segment(1)
         red.finish()
+        # KLAB_DDP_WIRE_DTYPE=bf16: gradients cross the wire in bf16 (stated departure): the mean within bf16 rounding, half the bytes
+        os.environ["KLAB_DDP_WIRE_DTYPE"] = "bf16"
+        try:
+            red16 = SegmentReducer(segs, None, max_bucket_elems=256)
+            assert red16.wire_dtype == torch.bfloat16
+            f3 = {"main": (torch.arange(1500, dtype=torch.float32) * 0.37 + 1.0) * (rank + 1), "swin": None}
+            red16.reduce_segment(0, f3)
+            red16.reduce_segment(1, f3)
+            red16.finish()
+            want = (torch.arange(1500, dtype=torch.float32) * 0.37 + 1.0) * (sum(range(1, world + 1)) / world)
+            ok = ok and float(((f3["main"] - want).abs() / want).max()) < 1.2e-2 and red16.stats()["bytes"] == 1500 * 2
+        finally:
+            del os.environ["KLAB_DDP_WIRE_DTYPE"]
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
