@@ -158,6 +158,22 @@ typedef struct klab_attn_args {
 } klab_attn_args;
 int klab_t5_attn_fwd(const klab_attn_args* a, void* stream);
 int klab_t5_attn_bwd(const klab_attn_args* a, void* stream);
+/* Front half of a T5 attention sub-layer in ONE launch (forward): T5LayerNorm (HF/t5:59-72) -> q|k|v projection (self, HF/t5:206-209)
+ * or q projection (cross) -> attention core (HF/t5:144-173), one workgroup per (sample, head).  Replaces klab_rmsnorm_fwd + the
+ * projection klab_gemm + klab_t5_attn_fwd of the serial chain; everything the backward pass reads is still written: xn (the
+ * normalised rows, bf16) and rstd, the projected q|k|v (self: [B*Lq, 3*inner] column blocks q | k | v; cross: q [B*Lq, inner]),
+ * attn.lse and attn.ctx.  attn.q / .k / .v are ignored for self attention; cross attention reads attn.k / attn.v (the projected
+ * encoder output).  Envelope: bf16, d_model = 512, head dim 64, Lq <= 64, Lk <= 64 (self: Lk == Lq); otherwise
+ * KLAB_ERR_UNSUPPORTED and the caller issues the three launches.                                                              */
+typedef struct klab_attn_fused_args {
+  const float* x; const float* gamma; float eps; int d_model;
+  const void* w;            /* bf16 projection rows: self q|k|v [3*inner, d_model]; cross q [inner, d_model] */
+  void* xn; float* rstd;    /* [B*Lq, d_model] bf16, [B*Lq] */
+  void* proj; long ldproj;
+  int cross;
+  klab_attn_args attn;
+} klab_attn_fused_args;
+int klab_t5_attn_fused_fwd(const klab_attn_fused_args* a, void* stream);
 /* dbias[H,Lq,Lk] += sum over nbatch slabs of ds_ws [nbatch, H, Lq, roundup(Lk,32)] (bf16), in a fixed order */
 int klab_dbias_reduce(const void* ds_ws, int dtype, float* dbias, int nbatch, int H, int Lq, int Lk, void* stream);
 

@@ -37,6 +37,11 @@ class AttnArgs(C.Structure):
                 ("score_scale", vp), ("bias_mod", i32)]
 
 
+class AttnFusedArgs(C.Structure):  # klab_attn_fused_args
+    _fields_ = [("x", vp), ("gamma", vp), ("eps", f32), ("d_model", i32), ("w", vp), ("xn", vp), ("rstd", vp), ("proj", vp), ("ldproj", i64),
+                ("cross", i32), ("attn", AttnArgs)]
+
+
 class SwinAttnArgs(C.Structure):
     _fields_ = [("dtype", i32), ("qkv", vp), ("ctx", vp), ("bias", vp), ("logit_scale", vp), ("lse", vp),
                 ("B", i32), ("R", i32), ("w", i32), ("shift", i32), ("H", i32), ("C", i32),
@@ -65,6 +70,7 @@ SIGNATURES = {
     "klab_layernorm_bwd_bias": [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, u32, vp],
     "klab_t5_attn_fwd": [C.POINTER(AttnArgs), vp],
     "klab_t5_attn_bwd": [C.POINTER(AttnArgs), vp],
+    "klab_t5_attn_fused_fwd": [C.POINTER(AttnFusedArgs), vp],
     "klab_t5_decode_attn": [i32, vp, i64, vp, vp, i64, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp],
     "klab_dbias_reduce": [vp, i32, vp, i32, i32, i32, i32, vp],
     "klab_swin_mlp_fused": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],

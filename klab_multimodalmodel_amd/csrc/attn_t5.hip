@@ -268,6 +268,7 @@ namespace klab {
 int t5_attn_fwd_mfma_dispatch(const klab_attn_args* a, hipStream_t s);  // attn_t5_mfma.hip
 int t5_attn_bwd_mfma_dispatch(const klab_attn_args* a, hipStream_t s);
 int dbias_reduce_dispatch(const void* ds_ws, float* dbias, int nbatch, int H, int Lq, int Lk, hipStream_t s);
+int t5_attn_fused_fwd_dispatch(const klab_attn_fused_args* fa, hipStream_t s);
 }
 using namespace klab;
 
@@ -314,6 +315,13 @@ extern "C" int klab_t5_attn_fwd(const klab_attn_args* a, void* stream) {
   }
   KLAB_LAUNCH_CHECK();
   return KLAB_OK;
+}
+
+extern "C" int klab_t5_attn_fused_fwd(const klab_attn_fused_args* fa, void* stream) {
+  if (!fa || !fa->x || !fa->gamma || !fa->w || !fa->xn || !fa->rstd || !fa->proj || !fa->attn.ctx) return KLAB_ERR_BADARG;
+  if (fa->cross && (!fa->attn.k || !fa->attn.v)) return KLAB_ERR_BADARG;
+  if (fa->attn.B <= 0) return KLAB_OK;
+  return t5_attn_fused_fwd_dispatch(fa, (hipStream_t)stream);
 }
 
 extern "C" int klab_t5_attn_bwd(const klab_attn_args* a, void* stream) {

@@ -90,33 +90,18 @@ __device__ __forceinline__ void stage(const bf16_t* __restrict__ g, long ld, int
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
+// one wave's 16 queries (q0 .. q0+15) against the staged keys / values of (b, h): scores, softmax, dropout, P V, stores.
+// qf = the wave's Q fragments (row q0 + (lane & 15), columns 32 ks + 8 (lane >> 4) .. + 7).
 template <int DK, int MAXT>
-__global__ __launch_bounds__(256) void t5_attn_fwd_mfma(AttnMP p) {
+__device__ __forceinline__ void attn_fwd_core(const AttnMP& p, const char* Kr, const char* Vt, const bf16x8 (&qf)[(DK + 31) / 32], int b, int h,
+                                              int q0, int lane) {
   constexpr int KS = (DK + 31) / 32, DKP = KS * 32, DT = (DK + 15) / 16;
   constexpr int KPITCH = DKP * 2 + 16;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int Lq = p.Lq, Lk = p.Lk;
   const int Lkp = (Lk + 31) & ~31, NT = Lkp / 16;
-  char* Kr = smem;
-  char* Vt = smem + (size_t)Lkp * KPITCH;
-  const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  stage<DK, DKP, true, false>(p.k, p.ldk, b, h, Lk, Lkp, Kr, KPITCH, nullptr);
-  stage<DK, DKP, false, true>(p.v, p.ldv, b, h, Lk, Lkp, nullptr, 0, Vt);
-  __syncthreads();
-  const int q0 = blockIdx.x * 64 + wave * 16;
-  if (q0 >= Lq) return;
   const int g = lane >> 4;
   const int q = q0 + (lane & 15);
   const int qc = q < Lq ? q : Lq - 1;
-  bf16x8 qf[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    const int c = ks * 32 + g * 8;
-    bf16x8 v = {};
-    if (c < DK) v = *reinterpret_cast<const bf16x8*>(p.q + ((long)b * Lq + qc) * p.ldq + (long)h * DK + c);
-    qf[ks] = v;
-  }
   f32x4 s[MAXT];
 #pragma unroll
   for (int t = 0; t < MAXT; ++t) {
@@ -186,6 +171,192 @@ __global__ __launch_bounds__(256) void t5_attn_fwd_mfma(AttnMP p) {
           bf16x4{(bf16_t)o[dt][0], (bf16_t)o[dt][1], (bf16_t)o[dt][2], (bf16_t)o[dt][3]};
     }
   }
+}
+
+template <int DK, int MAXT>
+__global__ __launch_bounds__(256) void t5_attn_fwd_mfma(AttnMP p) {
+  constexpr int KS = (DK + 31) / 32, DKP = KS * 32;
+  constexpr int KPITCH = DKP * 2 + 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int Lq = p.Lq, Lk = p.Lk;
+  const int Lkp = (Lk + 31) & ~31;
+  char* Kr = smem;
+  char* Vt = smem + (size_t)Lkp * KPITCH;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  stage<DK, DKP, true, false>(p.k, p.ldk, b, h, Lk, Lkp, Kr, KPITCH, nullptr);
+  stage<DK, DKP, false, true>(p.v, p.ldv, b, h, Lk, Lkp, nullptr, 0, Vt);
+  __syncthreads();
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  if (q0 >= Lq) return;
+  const int g = lane >> 4;
+  const int q = q0 + (lane & 15);
+  const int qc = q < Lq ? q : Lq - 1;
+  bf16x8 qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int c = ks * 32 + g * 8;
+    bf16x8 v = {};
+    if (c < DK) v = *reinterpret_cast<const bf16x8*>(p.q + ((long)b * Lq + qc) * p.ldq + (long)h * DK + c);
+    qf[ks] = v;
+  }
+  attn_fwd_core<DK, MAXT>(p, Kr, Vt, qf, b, h, q0, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused front half of a T5 attention sub-layer (forward): T5LayerNorm -> q|k|v (self) or q (cross) projection -> attention
+// (HF/t5:59-72 + :206-209, 281-369 + :144-173) in ONE launch, one workgroup per (sample, head).  For d_model = 512, head dim 64
+// and at most 64 queries / keys per sample (T5-small at the caption shapes: Le = 58, Lt = 64).  Replaces three launches of the
+// serial chain (klab_rmsnorm_fwd, the projection klab_gemm, klab_t5_attn_fwd); what the backward pass reads is still written:
+// the normalised rows (bf16) + 1/rms by the head-0 workgroup, the projected q|k|v in the fused projection buffer's layout,
+// the log-sum-exp.  The rows are normalised with klab_rmsnorm_fwd's own arithmetic (same summation order), the dropout masks
+// are the attention kernel's (same indices), so the unfused path and this one differ only in the projection's summation order.
+//   1. each wave normalises its 16 rows (fp32 in, bf16 out) into an LDS image [64 rows][512] (1-KiB rows, 16-byte chunk c of
+//      row r at position c ^ (r & 15): conflict-free b128 fragment reads);
+//   2. the head's projection rows (192 x 512 for q|k|v, 64 x 512 for q) stream through a 3-slot LDS-DMA ring in k-tiles of 64
+//      (128-byte rows, chunk c of row r at c ^ (r & 7)); per k-tile 2 x NJ MFMAs per wave, W as the A operand: a lane ends up
+//      with 4 consecutive projection columns of its row;
+//   3. q|k|v go to memory (bf16) and into the attention's LDS images (Q, K row images; V transposed-read image), which alias
+//      the ring; cross attention stages K / V from the projected encoder output instead;
+//   4. attn_fwd_core, unchanged.
+struct AttnFusedP {
+  const float* x; const float* gamma; float eps;
+  const bf16_t* w;             // SELF: [3 * inner, 512] rows q | k | v; CROSS: [inner, 512] rows q
+  bf16_t* xn; float* rstd;     // [B * Lq, 512], [B * Lq]
+  bf16_t* proj; long ldproj;   // SELF: [B * Lq, 3 * inner]; CROSS: [B * Lq, inner]
+  AttnMP a;
+};
+constexpr int AF_D = 512, AF_DK = 64, AF_S = 3;
+template <bool CROSS>
+__global__ __launch_bounds__(256) void t5_attn_fused_fwd(AttnFusedP f) {
+  constexpr int D = AF_D, DK = AF_DK, NROWS = CROSS ? 64 : 192, NJ = NROWS / 16, SLOT = NROWS * 128, LPW = NROWS / 32;
+  constexpr int KPITCH = DK * 2 + 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Xs = smem;                // 64 KiB
+  char* ring = smem + 64 * 1024;  // AF_S slots; later the attention images
+  const AttnMP& p = f.a;
+  const int Lq = p.Lq, inner = p.H * DK;
+  const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4;
+
+  // projection rows through the ring: image row i <- weight row (i / 64) * inner + h * 64 + i % 64
+  const bf16_t* wsrc[LPW];
+#pragma unroll
+  for (int i = 0; i < LPW; ++i) {
+    const int r = (wave * LPW + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ (lane >> 3);
+    wsrc[i] = f.w + ((long)(r >> 6) * inner + h * 64 + (r & 63)) * D + c * 8;
+  }
+  auto issue = [&](int kt) {
+    if (kt >= D / 64) return;
+    char* st = ring + (kt % AF_S) * SLOT;
+#pragma unroll
+    for (int i = 0; i < LPW; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + kt * 64),
+                                       (__attribute__((address_space(3))) void*)(st + (wave * LPW + i) * 1024), 16, 0, 0);
+  };
+  issue(0);
+  issue(1);
+
+  // 1. T5LayerNorm of the wave's 16 rows (klab_rmsnorm_fwd's arithmetic: two float4 per lane, wave sum, rsqrt).  Eight rows are
+  //    requested before the first is used (a row at a time exposed one memory round trip per row: 16 in a row per wave)
+  {
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(f.gamma + lane * 4), g1 = *reinterpret_cast<const f32x4*>(f.gamma + 256 + lane * 4);
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      f32x4 v0[8], v1[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = wave * 16 + half * 8 + i;
+        const long grow = (long)b * Lq + (r < Lq ? r : Lq - 1);  // clamped: rows past the sequence are zeroed below
+        v0[i] = *reinterpret_cast<const f32x4*>(f.x + grow * D + lane * 4);
+        v1[i] = *reinterpret_cast<const f32x4*>(f.x + grow * D + 256 + lane * 4);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = wave * 16 + half * 8 + i;
+        const bool valid = r < Lq;
+        const float z = valid ? 1.f : 0.f;
+        const f32x4 a0 = v0[i] * z, a1 = v1[i] * z;
+        float ss = a0[0] * a0[0] + a0[1] * a0[1] + a0[2] * a0[2] + a0[3] * a0[3];
+        ss += a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2] + a1[3] * a1[3];
+        ss = wave_sum(ss);
+        const float rs = rsqrtf(ss / (float)D + f.eps);
+        const bf16x4 o0 = bf16x4{(bf16_t)(g0[0] * (a0[0] * rs)), (bf16_t)(g0[1] * (a0[1] * rs)), (bf16_t)(g0[2] * (a0[2] * rs)), (bf16_t)(g0[3] * (a0[3] * rs))};
+        const bf16x4 o1 = bf16x4{(bf16_t)(g1[0] * (a1[0] * rs)), (bf16_t)(g1[1] * (a1[1] * rs)), (bf16_t)(g1[2] * (a1[2] * rs)), (bf16_t)(g1[3] * (a1[3] * rs))};
+        // columns 4 lane .. + 3 = half (lane & 1) of chunk lane >> 1; columns 256 + 4 lane: chunk 32 + (lane >> 1)
+        const int sw = r & 15;
+        *reinterpret_cast<bf16x4*>(Xs + r * 1024 + (((lane >> 1) ^ sw) * 16) + (lane & 1) * 8) = o0;
+        *reinterpret_cast<bf16x4*>(Xs + r * 1024 + (((32 + (lane >> 1)) ^ sw) * 16) + (lane & 1) * 8) = o1;
+        if (h == 0 && valid) {
+          const long grow = (long)b * Lq + r;
+          *reinterpret_cast<bf16x4*>(f.xn + grow * D + lane * 4) = o0;
+          *reinterpret_cast<bf16x4*>(f.xn + grow * D + 256 + lane * 4) = o1;
+          if (lane == 0) f.rstd[grow] = rs;
+        }
+      }
+    }
+  }
+
+  // 2. projection: acc[j][r] = out[row 16 wave + (lane & 15)][column 16 j + 4 g + r]
+  f32x4 acc[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int xr = wave * 16 + (lane & 15);
+  for (int kt = 0; kt < D / 64; ++kt) {
+    if (kt + 1 < D / 64) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // raw barrier: a __syncthreads() carries a fence that drains vmcnt, i.e. the k-tile still in flight.  (A wave reads only its
+    // OWN normalised rows, written by itself in program order: no barrier is needed for those.)
+    __builtin_amdgcn_s_barrier();
+    const char* Ws = ring + (kt % AF_S) * SLOT;
+    issue(kt + 2);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 xf = *reinterpret_cast<const bf16x8*>(Xs + xr * 1024 + (((8 * kt + 4 * ks + g) ^ (xr & 15)) * 16));
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int wr = j * 16 + (lane & 15);
+        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(Ws + wr * 128 + (((4 * ks + g) ^ (wr & 7)) * 16));
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[j], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();  // every wave is done with the ring: it becomes the attention's images
+
+  // 3. q | k | v -> memory and LDS images
+  const int Lk = p.Lk, Lkp = (Lk + 31) & ~31;
+  char* Qr = ring;
+  char* Kr = Qr + 64 * KPITCH;
+  char* Vt = Kr + 64 * KPITCH;  // (64 rows each whatever Lk is: the self form writes all 64 projected rows)
+  {
+    const int R = xr;
+    const long grow = (long)b * Lq + R;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int blk = j >> 2, nn = (j & 3) * 16 + g * 4;  // 0: q, 1: k, 2: v; column inside the head
+      const bf16x4 o = bf16x4{(bf16_t)acc[j][0], (bf16_t)acc[j][1], (bf16_t)acc[j][2], (bf16_t)acc[j][3]};
+      if (R < Lq) *reinterpret_cast<bf16x4*>(f.proj + grow * f.ldproj + (long)blk * inner + h * DK + nn) = o;
+      if (blk == 0) *reinterpret_cast<bf16x4*>(Qr + R * KPITCH + nn * 2) = o;
+      else if (blk == 1) *reinterpret_cast<bf16x4*>(Kr + R * KPITCH + nn * 2) = o;
+      else *reinterpret_cast<bf16x4*>(Vt + TrImg<DK>::off(R, nn)) = o;
+    }
+  }
+  if constexpr (CROSS) {
+    stage<DK, DK, true, false>(p.k, p.ldk, b, h, Lk, Lkp, Kr, KPITCH, nullptr);
+    stage<DK, DK, false, true>(p.v, p.ldv, b, h, Lk, Lkp, nullptr, 0, Vt);
+  }
+  __syncthreads();
+
+  // 4. attention of the wave's 16 queries
+  const int q0 = wave * 16;
+  if (q0 >= Lq) return;
+  bf16x8 qf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) qf[ks] = row_frag(Qr, KPITCH, q0, ks, lane);
+  attn_fwd_core<DK, 4>(p, Kr, Vt, qf, b, h, q0, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1193,6 +1364,32 @@ static int t5_flash_fallback(const AttnMP& p, int dk, bool backward, hipStream_t
     hipLaunchKernelGGL(dbias_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, p.ds_ws, p.dbias, p.B, p.H * p.Lq, p.Lk, Lkp);
     KLAB_LAUNCH_CHECK();
   }
+  return KLAB_OK;
+}
+
+// fused front half of an attention sub-layer (see t5_attn_fused_fwd); KLAB_ERR_UNSUPPORTED outside its envelope
+int t5_attn_fused_fwd_dispatch(const klab_attn_fused_args* fa, hipStream_t s) {
+  const klab_attn_args* a = &fa->attn;
+  if (a->dtype != KLAB_BF16 || fa->d_model != AF_D || a->dk != AF_DK || a->Lq < 1 || a->Lq > 64 || a->Lk < 1 || a->Lk > 64) return KLAB_ERR_UNSUPPORTED;
+  if (!fa->cross && a->Lk != a->Lq) return KLAB_ERR_UNSUPPORTED;
+  if ((a->ldo & 3) || (fa->ldproj & 3) || (fa->cross && ((a->ldk & 7) || (a->ldv & 7)))) return KLAB_ERR_UNSUPPORTED;
+  if (a->score_scale || a->bias_mod) return KLAB_ERR_UNSUPPORTED;
+  AttnFusedP f;
+  f.x = fa->x; f.gamma = fa->gamma; f.eps = fa->eps; f.w = (const bf16_t*)fa->w; f.xn = (bf16_t*)fa->xn; f.rstd = fa->rstd;
+  f.proj = (bf16_t*)fa->proj; f.ldproj = fa->ldproj;
+  f.a = to_mp(a);
+  const size_t images = 2 * (size_t)64 * (AF_DK * 2 + 16) + TrImg<AF_DK>::bytes(64);
+  const size_t ring = (size_t)AF_S * (fa->cross ? 64 : 192) * 128;
+  const size_t lds = 64 * 1024 + (ring > images ? ring : images);
+  int rc;
+  if (fa->cross) {
+    rc = set_lds_attr(t5_attn_fused_fwd<true>, lds); if (rc) return rc;
+    hipLaunchKernelGGL(t5_attn_fused_fwd<true>, dim3(a->B * a->H), dim3(256), lds, s, f);
+  } else {
+    rc = set_lds_attr(t5_attn_fused_fwd<false>, lds); if (rc) return rc;
+    hipLaunchKernelGGL(t5_attn_fused_fwd<false>, dim3(a->B * a->H), dim3(256), lds, s, f);
+  }
+  KLAB_LAUNCH_CHECK();
   return KLAB_OK;
 }
 

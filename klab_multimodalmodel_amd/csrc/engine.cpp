@@ -716,6 +716,12 @@ int t5_sublayer_out(const Ctx& c, const void* x, int M, int K, long woffv, int d
   return fwd_gemm(c, g, woffv);
 }
 
+// A/B switch of the fused attention front half (klab_t5_attn_fused_fwd): KLAB_T5_ATTN_FUSED=0 keeps the three launches
+static bool attn_fused_on() {
+  static const bool on = [] { const char* v = getenv("KLAB_T5_ATTN_FUSED"); return !v || atoi(v) != 0; }();
+  return on;
+}
+
 // ------------------------------------------------------------------------------------------------
 // T5 stack forward (HF/t5:663-750); `h[0]` must already hold dropout(inputs_embeds)
 // ------------------------------------------------------------------------------------------------
@@ -731,8 +737,6 @@ int t5_stack_forward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Par
     const T5LayerIdx& l = L[i];
     T5LayerBufs& b = s.L[i];
     // --- self attention (HF/t5:372-401) ---
-    RC(rms_fwd_for_linear(c, s.h[j], W[l.ln0], b.xn1, b.rstd1, M, d, cfg.ln_eps));
-    RC(linear_fwd(c, b.xn1, M, d, P[l.q].warena_off, 3 * inner, b.qkv, 3 * inner, c.dt));
     {
       klab_attn_args a;
       memset(&a, 0, sizeof(a));
@@ -740,13 +744,26 @@ int t5_stack_forward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Par
       a.v = eoff(c, b.qkv, 2 * inner); a.ldv = 3 * inner; a.bias = s.bias; a.causal = dec ? 1 : 0;
       a.ctx = b.ctx; a.ldo = inner; a.lse = b.lse; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lq; a.dk = dk;
       a.drop_p = p; a.seed_dev = c.e->seed_dev; a.drop_tag = tag_of(stack_id, (int)i, SITE_PROB);
-      RC(klab_t5_attn_fwd(&a, c.ws()));
+      // one launch for norm -> q|k|v -> attention where the fused kernel's envelope allows (bf16, d_model 512, head dim 64, <= 64
+      // tokens per sample: T5-small at the caption shapes); otherwise the three launches
+      int frc = KLAB_ERR_UNSUPPORTED;
+      if (attn_fused_on() && c.dt == KLAB_BF16 && !c.e->fp8 && Lq >= 32) {  // (the 9-token language encoder: one row tile per sample would stream the weights for nothing)
+        klab_attn_fused_args fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.x = s.h[j]; fa.gamma = W[l.ln0]; fa.eps = cfg.ln_eps; fa.d_model = d; fa.w = woff(c, P[l.q].warena_off);
+        fa.xn = b.xn1; fa.rstd = b.rstd1; fa.proj = b.qkv; fa.ldproj = 3 * inner; fa.cross = 0; fa.attn = a;
+        frc = klab_t5_attn_fused_fwd(&fa, c.ws());
+        if (frc != 0 && frc != KLAB_ERR_UNSUPPORTED) return frc;
+      }
+      if (frc != 0) {
+        RC(rms_fwd_for_linear(c, s.h[j], W[l.ln0], b.xn1, b.rstd1, M, d, cfg.ln_eps));
+        RC(linear_fwd(c, b.xn1, M, d, P[l.q].warena_off, 3 * inner, b.qkv, 3 * inner, c.dt));
+        RC(klab_t5_attn_fwd(&a, c.ws()));
+      }
     }
     RC(t5_sublayer_out(c, b.ctx, M, inner, P[l.o].warena_off, d, s.h[j], s.h[j + 1], p, tag_of(stack_id, (int)i, SITE_ATTN_OUT)));
     ++j;
     if (dec) {  // --- cross attention (HF/t5:404-432), K/V of all layers projected once ---
-      RC(rms_fwd_for_linear(c, s.h[j], W[l.ln1], b.xn2, b.rstd2, M, d, cfg.ln_eps));
-      RC(linear_fwd(c, b.xn2, M, d, P[l.cq].warena_off, inner, b.qc, inner, c.dt));
       klab_attn_args a;
       memset(&a, 0, sizeof(a));
       a.dtype = c.dt; a.q = b.qc; a.ldq = inner;
@@ -755,7 +772,20 @@ int t5_stack_forward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Par
       a.bias = nullptr; a.causal = 0; a.ctx = b.ctx2; a.ldo = inner; a.lse = b.lse2;
       a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lkv; a.dk = dk;
       a.drop_p = p; a.seed_dev = c.e->seed_dev; a.drop_tag = tag_of(stack_id, (int)i, SITE_XPROB);
-      RC(klab_t5_attn_fwd(&a, c.ws()));
+      int frc = KLAB_ERR_UNSUPPORTED;
+      if (attn_fused_on() && c.dt == KLAB_BF16 && !c.e->fp8 && Lq >= 32) {  // norm -> q projection -> attention over the projected encoder output
+        klab_attn_fused_args fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.x = s.h[j]; fa.gamma = W[l.ln1]; fa.eps = cfg.ln_eps; fa.d_model = d; fa.w = woff(c, P[l.cq].warena_off);
+        fa.xn = b.xn2; fa.rstd = b.rstd2; fa.proj = b.qc; fa.ldproj = inner; fa.cross = 1; fa.attn = a;
+        frc = klab_t5_attn_fused_fwd(&fa, c.ws());
+        if (frc != 0 && frc != KLAB_ERR_UNSUPPORTED) return frc;
+      }
+      if (frc != 0) {
+        RC(rms_fwd_for_linear(c, s.h[j], W[l.ln1], b.xn2, b.rstd2, M, d, cfg.ln_eps));
+        RC(linear_fwd(c, b.xn2, M, d, P[l.cq].warena_off, inner, b.qc, inner, c.dt));
+        RC(klab_t5_attn_fwd(&a, c.ws()));
+      }
       RC(t5_sublayer_out(c, b.ctx2, M, inner, P[l.co].warena_off, d, s.h[j], s.h[j + 1], p, tag_of(stack_id, (int)i, SITE_XOUT)));
       ++j;
     }

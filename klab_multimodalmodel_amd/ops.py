@@ -189,6 +189,20 @@ def t5_attn_fwd(q, k, v, ctx, lse, *, B, H, Lq, Lk, dk, bias=None, causal=False,
     L.check(lib.klab_t5_attn_fwd(C.byref(a), L.stream_ptr()), "klab_t5_attn_fwd")
 
 
+def t5_attn_fused_fwd(x, gamma, w, xn, rstd, proj, ctx, lse, *, B, H, Lq, Lk, dk, eps=1e-6, bias=None, causal=False, cross=False, k=None, v=None,
+                      ldk=None, ldv=None, drop_p=0.0, seed=None, tag=0):
+    """T5LayerNorm -> q|k|v (self) / q (cross) projection -> attention in one launch (klab_t5_attn_fused_fwd); NotImplementedError
+    outside the envelope (bf16, d_model 512, head dim 64, at most 64 queries / keys)"""
+    lib = L.load()
+    fa = L.AttnFusedArgs()
+    fa.x, fa.gamma, fa.eps, fa.d_model = x.data_ptr(), gamma.data_ptr(), eps, x.shape[1]
+    fa.w, fa.xn, fa.rstd, fa.proj, fa.ldproj, fa.cross = w.data_ptr(), xn.data_ptr(), rstd.data_ptr(), proj.data_ptr(), proj.stride(0), int(cross)
+    kk, vv = (k, v) if cross else (proj, proj)
+    fa.attn = _attn_args(proj, kk, vv, ctx, lse, bias, causal, B, H, Lq, Lk, dk, drop_p, seed, tag, proj.stride(0),
+                         ldk or kk.stride(0), ldv or vv.stride(0), ctx.stride(0))
+    L.check(lib.klab_t5_attn_fused_fwd(C.byref(fa), L.stream_ptr()), "klab_t5_attn_fused_fwd")
+
+
 def t5_attn_bwd(q, k, v, ctx, lse, dctx, dq, dk_out, dv, *, B, H, Lq, Lk, dk, bias=None, causal=False, dbias=None,
                 drop_p=0.0, seed=None, tag=0, ldq=None, ldk=None, ldv=None, ldo=None, lddo=None, lddq=None, lddk=None,
                 lddv=None, ds_ws=None):
