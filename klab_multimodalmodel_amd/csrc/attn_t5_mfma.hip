@@ -209,13 +209,13 @@ __global__ __launch_bounds__(256) void t5_attn_fwd_mfma(AttnMP p) {
 // and at most 64 queries / keys per sample (T5-small at the caption shapes: Le = 58, Lt = 64).  Replaces three launches of the
 // serial chain (klab_rmsnorm_fwd, the projection klab_gemm, klab_t5_attn_fwd); what the backward pass reads is still written:
 // the normalised rows (bf16) + 1/rms by the head-0 workgroup, the projected q|k|v in the fused projection buffer's layout,
-// the log-sum-exp.  The rows are normalised with klab_rmsnorm_fwd's own arithmetic (same summation order), the dropout masks
-// are the attention kernel's (same indices), so the unfused path and this one differ only in the projection's summation order.
-//   1. each wave normalises its 16 rows (fp32 in, bf16 out) into an LDS image [64 rows][512] (1-KiB rows, 16-byte chunk c of
-//      row r at position c ^ (r & 15): conflict-free b128 fragment reads);
+// the log-sum-exp.  The dropout masks are the attention kernel's (same indices); the unfused path and this one differ only in
+// summation order (sum of squares, projection).
+//   1. each lane normalises ITS 128 values of a row (row 16 wave + (lane & 15), columns 32 ks + 8 (lane >> 4) .. + 7) straight
+//      into the projection's B-operand fragments: the normalised rows never pass through LDS;
 //   2. the head's projection rows (192 x 512 for q|k|v, 64 x 512 for q) stream through a 3-slot LDS-DMA ring in k-tiles of 64
 //      (128-byte rows, chunk c of row r at c ^ (r & 7)); per k-tile 2 x NJ MFMAs per wave, W as the A operand: a lane ends up
-//      with 4 consecutive projection columns of its row;
+//      with 4 consecutive projection columns of its row; 72 KiB of LDS, two workgroups per CU;
 //   3. q|k|v go to memory (bf16) and into the attention's LDS images (Q, K row images; V transposed-read image), which alias
 //      the ring; cross attention stages K / V from the projected encoder output instead;
 //   4. attn_fwd_core, unchanged.
@@ -225,18 +225,29 @@ struct AttnFusedP {
   bf16_t* xn; float* rstd;     // [B * Lq, 512], [B * Lq]
   bf16_t* proj; long ldproj;   // SELF: [B * Lq, 3 * inner]; CROSS: [B * Lq, inner]
   AttnMP a;
+  int ablate;  // diagnostics (KLAB_AF_ABLATE): 1 = no attention core, 2 = no projection MFMAs / weight stream, 4 = no q|k|v copy-out
 };
 constexpr int AF_D = 512, AF_DK = 64, AF_S = 3;
 template <bool CROSS>
-__global__ __launch_bounds__(256) void t5_attn_fused_fwd(AttnFusedP f) {
+__global__ __launch_bounds__(256, 2) void t5_attn_fused_fwd(AttnFusedP f) {
   constexpr int D = AF_D, DK = AF_DK, NROWS = CROSS ? 64 : 192, NJ = NROWS / 16, SLOT = NROWS * 128, LPW = NROWS / 32;
-  constexpr int KPITCH = DK * 2 + 16;
+  constexpr int KPITCH = DK * 2 + 16, NKS = D / 32;
+  constexpr int IMAGES = 3 * 64 * KPITCH + (int)TrImg<DK>::bytes(64);
+  constexpr int GAMMA_OFF = (AF_S * SLOT > IMAGES ? AF_S * SLOT : IMAGES);
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Xs = smem;                // 64 KiB
-  char* ring = smem + 64 * 1024;  // AF_S slots; later the attention images
+  char* ring = smem;  // AF_S slots of the weight stream; later the attention images
   const AttnMP& p = f.a;
   const int Lq = p.Lq, inner = p.H * DK;
-  const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
+  // Workgroup -> (sample, head).  The H workgroups of a sample all read its fp32 rows (H x 128 KiB at 64 rows): dealt round-robin
+  // over the 8 XCDs as consecutive block ids, every XCD's L2 fetched every sample (64 MB through the fabric at B = 64, ~13 us of
+  // the kernel).  Blocks i and i + 8 share an XCD, so the heads of one sample are given block ids that are equal mod 8: its rows
+  // are fetched into ONE L2 and hit there H - 1 times.  Speed only; any mapping is correct.
+  int b, h;
+  {
+    const int i = blockIdx.x;
+    if ((p.B & 7) == 0) { const int xcd = i & 7, k = i >> 3; h = k % p.H; b = (k / p.H) * 8 + xcd; }
+    else { b = i / p.H; h = i % p.H; }
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4;
@@ -257,46 +268,49 @@ __global__ __launch_bounds__(256) void t5_attn_fused_fwd(AttnFusedP f) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + kt * 64),
                                        (__attribute__((address_space(3))) void*)(st + (wave * LPW + i) * 1024), 16, 0, 0);
   };
-  issue(0);
-  issue(1);
+  if (!(f.ablate & 2)) { issue(0); issue(1); }
+  // the norm weight goes through LDS (2 KiB behind the ring): read from memory inside the fragment loop below, hipcc waited for
+  // every pair of loads before issuing the next one -- sixteen L2 round trips in a row per wave, ~10 us of a 30 us kernel
+  float* gs = reinterpret_cast<float*>(smem + GAMMA_OFF);
+  *reinterpret_cast<f32x2*>(gs + tid * 2) = *reinterpret_cast<const f32x2*>(f.gamma + tid * 2);
 
-  // 1. T5LayerNorm of the wave's 16 rows (klab_rmsnorm_fwd's arithmetic: two float4 per lane, wave sum, rsqrt).  Eight rows are
-  //    requested before the first is used (a row at a time exposed one memory round trip per row: 16 in a row per wave)
+  // 1. T5LayerNorm straight into MFMA fragments: lane (row 16 wave + (lane & 15), g = lane >> 4) owns columns 32 ks + 8 g .. + 7
+  //    of its row for ks = 0 .. 15 -- the B-operand fragments of the projection -- so the normalised rows never pass through LDS
+  //    (a first form staged them in a 64 KiB image: one workgroup per CU, 60 us per launch against 41 us for the three launches).
+  //    Sum of squares: in-lane over the 128 values, then over the four lanes of the row (two shuffles).
+  const int xr = wave * 16 + (lane & 15);
+  const bool xvalid = xr < Lq;
+  const long xrow = (long)b * Lq + (xvalid ? xr : Lq - 1);
+  bf16x8 xf[NKS];
   {
-    const f32x4 g0 = *reinterpret_cast<const f32x4*>(f.gamma + lane * 4), g1 = *reinterpret_cast<const f32x4*>(f.gamma + 256 + lane * 4);
-#pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-      f32x4 v0[8], v1[8];
+    const float* xp = f.x + xrow * D + g * 8;
+    float ss = 0.f;
+    f32x4 raw[NKS][2];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int r = wave * 16 + half * 8 + i;
-        const long grow = (long)b * Lq + (r < Lq ? r : Lq - 1);  // clamped: rows past the sequence are zeroed below
-        v0[i] = *reinterpret_cast<const f32x4*>(f.x + grow * D + lane * 4);
-        v1[i] = *reinterpret_cast<const f32x4*>(f.x + grow * D + 256 + lane * 4);
-      }
+    for (int ks = 0; ks < NKS; ++ks) {
+      raw[ks][0] = *reinterpret_cast<const f32x4*>(xp + ks * 32);
+      raw[ks][1] = *reinterpret_cast<const f32x4*>(xp + ks * 32 + 4);
+    }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int r = wave * 16 + half * 8 + i;
-        const bool valid = r < Lq;
-        const float z = valid ? 1.f : 0.f;
-        const f32x4 a0 = v0[i] * z, a1 = v1[i] * z;
-        float ss = a0[0] * a0[0] + a0[1] * a0[1] + a0[2] * a0[2] + a0[3] * a0[3];
-        ss += a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2] + a1[3] * a1[3];
-        ss = wave_sum(ss);
-        const float rs = rsqrtf(ss / (float)D + f.eps);
-        const bf16x4 o0 = bf16x4{(bf16_t)(g0[0] * (a0[0] * rs)), (bf16_t)(g0[1] * (a0[1] * rs)), (bf16_t)(g0[2] * (a0[2] * rs)), (bf16_t)(g0[3] * (a0[3] * rs))};
-        const bf16x4 o1 = bf16x4{(bf16_t)(g1[0] * (a1[0] * rs)), (bf16_t)(g1[1] * (a1[1] * rs)), (bf16_t)(g1[2] * (a1[2] * rs)), (bf16_t)(g1[3] * (a1[3] * rs))};
-        // columns 4 lane .. + 3 = half (lane & 1) of chunk lane >> 1; columns 256 + 4 lane: chunk 32 + (lane >> 1)
-        const int sw = r & 15;
-        *reinterpret_cast<bf16x4*>(Xs + r * 1024 + (((lane >> 1) ^ sw) * 16) + (lane & 1) * 8) = o0;
-        *reinterpret_cast<bf16x4*>(Xs + r * 1024 + (((32 + (lane >> 1)) ^ sw) * 16) + (lane & 1) * 8) = o1;
-        if (h == 0 && valid) {
-          const long grow = (long)b * Lq + r;
-          *reinterpret_cast<bf16x4*>(f.xn + grow * D + lane * 4) = o0;
-          *reinterpret_cast<bf16x4*>(f.xn + grow * D + 256 + lane * 4) = o1;
-          if (lane == 0) f.rstd[grow] = rs;
-        }
-      }
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ss += raw[ks][0][u] * raw[ks][0][u] + raw[ks][1][u] * raw[ks][1][u];
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    const float rs = xvalid ? rsqrtf(ss / (float)D + f.eps) : 0.f;  // rows past the sequence project to zero
+    __syncthreads();  // the norm weight is in LDS (the fence also waits for the row loads, which are needed here anyway)
+    const float* gp = gs + g * 8;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp + ks * 32), g1 = *reinterpret_cast<const f32x4*>(gp + ks * 32 + 4);
+      const f32x4 a0 = raw[ks][0], a1 = raw[ks][1];
+      xf[ks] = bf16x8{(bf16_t)(g0[0] * (a0[0] * rs)), (bf16_t)(g0[1] * (a0[1] * rs)), (bf16_t)(g0[2] * (a0[2] * rs)), (bf16_t)(g0[3] * (a0[3] * rs)),
+                      (bf16_t)(g1[0] * (a1[0] * rs)), (bf16_t)(g1[1] * (a1[1] * rs)), (bf16_t)(g1[2] * (a1[2] * rs)), (bf16_t)(g1[3] * (a1[3] * rs))};
+    }
+    if (h == 0 && xvalid) {  // what the backward pass reads: normalised rows + 1/rms, written once per sample (by its head-0 workgroup)
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) *reinterpret_cast<bf16x8*>(f.xn + xrow * D + ks * 32 + g * 8) = xf[ks];
+      if (g == 0) f.rstd[xrow] = rs;
     }
   }
 
@@ -304,44 +318,46 @@ __global__ __launch_bounds__(256) void t5_attn_fused_fwd(AttnFusedP f) {
   f32x4 acc[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int xr = wave * 16 + (lane & 15);
+  if (!(f.ablate & 2))
+#pragma unroll
   for (int kt = 0; kt < D / 64; ++kt) {
     if (kt + 1 < D / 64) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // raw barrier: a __syncthreads() carries a fence that drains vmcnt, i.e. the k-tile still in flight.  (A wave reads only its
-    // OWN normalised rows, written by itself in program order: no barrier is needed for those.)
+    // raw barrier: a __syncthreads() carries a fence that drains vmcnt, i.e. the k-tile still in flight
     __builtin_amdgcn_s_barrier();
     const char* Ws = ring + (kt % AF_S) * SLOT;
     issue(kt + 2);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const bf16x8 xf = *reinterpret_cast<const bf16x8*>(Xs + xr * 1024 + (((8 * kt + 4 * ks + g) ^ (xr & 15)) * 16));
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const int wr = j * 16 + (lane & 15);
         const bf16x8 wf = *reinterpret_cast<const bf16x8*>(Ws + wr * 128 + (((4 * ks + g) ^ (wr & 7)) * 16));
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[2 * kt + ks], acc[j], 0, 0, 0);
       }
     }
   }
   __syncthreads();  // every wave is done with the ring: it becomes the attention's images
 
-  // 3. q | k | v -> memory and LDS images
+  // 3. q | k | v -> LDS images (Q, K, V row images for the attention and the copy-out; V also as a transposed-read image), then to
+  //    memory as whole 128-byte head slices (straight from the accumulators a store instruction wrote 32-byte pieces of 16 rows)
   const int Lk = p.Lk, Lkp = (Lk + 31) & ~31;
   char* Qr = ring;
   char* Kr = Qr + 64 * KPITCH;
-  char* Vt = Kr + 64 * KPITCH;  // (64 rows each whatever Lk is: the self form writes all 64 projected rows)
+  char* Vr = Kr + 64 * KPITCH;  // (64 rows each whatever Lk is: the self form writes all 64 projected rows)
+  char* Vt = Vr + 64 * KPITCH;
   {
     const int R = xr;
-    const long grow = (long)b * Lq + R;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int blk = j >> 2, nn = (j & 3) * 16 + g * 4;  // 0: q, 1: k, 2: v; column inside the head
       const bf16x4 o = bf16x4{(bf16_t)acc[j][0], (bf16_t)acc[j][1], (bf16_t)acc[j][2], (bf16_t)acc[j][3]};
-      if (R < Lq) *reinterpret_cast<bf16x4*>(f.proj + grow * f.ldproj + (long)blk * inner + h * DK + nn) = o;
       if (blk == 0) *reinterpret_cast<bf16x4*>(Qr + R * KPITCH + nn * 2) = o;
       else if (blk == 1) *reinterpret_cast<bf16x4*>(Kr + R * KPITCH + nn * 2) = o;
-      else *reinterpret_cast<bf16x4*>(Vt + TrImg<DK>::off(R, nn)) = o;
+      else {
+        *reinterpret_cast<bf16x4*>(Vr + R * KPITCH + nn * 2) = o;
+        *reinterpret_cast<bf16x4*>(Vt + TrImg<DK>::off(R, nn)) = o;
+      }
     }
   }
   if constexpr (CROSS) {
@@ -349,10 +365,24 @@ __global__ __launch_bounds__(256) void t5_attn_fused_fwd(AttnFusedP f) {
     stage<DK, DK, false, true>(p.v, p.ldv, b, h, Lk, Lkp, nullptr, 0, Vt);
   }
   __syncthreads();
+  if (!(f.ablate & 4)) {
+    constexpr int NB = CROSS ? 1 : 3;
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+      const char* img = blk == 0 ? Qr : (blk == 1 ? Kr : Vr);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int ch = tid + u * 256, row = ch >> 3, cc = ch & 7;
+        if (row < Lq)
+          *reinterpret_cast<bf16x8*>(f.proj + ((long)b * Lq + row) * f.ldproj + (long)blk * inner + h * DK + cc * 8) =
+              *reinterpret_cast<const bf16x8*>(img + row * KPITCH + cc * 16);
+      }
+    }
+  }
 
   // 4. attention of the wave's 16 queries
   const int q0 = wave * 16;
-  if (q0 >= Lq) return;
+  if (q0 >= Lq || (f.ablate & 1)) return;
   bf16x8 qf[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) qf[ks] = row_frag(Qr, KPITCH, q0, ks, lane);
@@ -1372,15 +1402,17 @@ int t5_attn_fused_fwd_dispatch(const klab_attn_fused_args* fa, hipStream_t s) {
   const klab_attn_args* a = &fa->attn;
   if (a->dtype != KLAB_BF16 || fa->d_model != AF_D || a->dk != AF_DK || a->Lq < 1 || a->Lq > 64 || a->Lk < 1 || a->Lk > 64) return KLAB_ERR_UNSUPPORTED;
   if (!fa->cross && a->Lk != a->Lq) return KLAB_ERR_UNSUPPORTED;
-  if ((a->ldo & 3) || (fa->ldproj & 3) || (fa->cross && ((a->ldk & 7) || (a->ldv & 7)))) return KLAB_ERR_UNSUPPORTED;
+  if ((a->ldo & 3) || (fa->ldproj & 7) || ((uintptr_t)fa->proj & 15) || (fa->cross && ((a->ldk & 7) || (a->ldv & 7)))) return KLAB_ERR_UNSUPPORTED;
   if (a->score_scale || a->bias_mod) return KLAB_ERR_UNSUPPORTED;
   AttnFusedP f;
   f.x = fa->x; f.gamma = fa->gamma; f.eps = fa->eps; f.w = (const bf16_t*)fa->w; f.xn = (bf16_t*)fa->xn; f.rstd = fa->rstd;
   f.proj = (bf16_t*)fa->proj; f.ldproj = fa->ldproj;
   f.a = to_mp(a);
-  const size_t images = 2 * (size_t)64 * (AF_DK * 2 + 16) + TrImg<AF_DK>::bytes(64);
+  static const int abl = [] { const char* e = getenv("KLAB_AF_ABLATE"); return e ? atoi(e) : 0; }();
+  f.ablate = abl;
+  const size_t images = 3 * (size_t)64 * (AF_DK * 2 + 16) + TrImg<AF_DK>::bytes(64);
   const size_t ring = (size_t)AF_S * (fa->cross ? 64 : 192) * 128;
-  const size_t lds = 64 * 1024 + (ring > images ? ring : images);
+  const size_t lds = (ring > images ? ring : images) + AF_D * 4;  // + the norm weight
   int rc;
   if (fa->cross) {
     rc = set_lds_attr(t5_attn_fused_fwd<true>, lds); if (rc) return rc;
