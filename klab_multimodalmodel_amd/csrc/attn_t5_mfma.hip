@@ -233,7 +233,8 @@ __global__ __launch_bounds__(256, 2) void t5_attn_fused_fwd(AttnFusedP f) {
   constexpr int D = AF_D, DK = AF_DK, NROWS = CROSS ? 64 : 192, NJ = NROWS / 16, SLOT = NROWS * 128, LPW = NROWS / 32;
   constexpr int KPITCH = DK * 2 + 16, NKS = D / 32;
   constexpr int IMAGES = 3 * 64 * KPITCH + (int)TrImg<DK>::bytes(64);
-  constexpr int GAMMA_OFF = (AF_S * SLOT > IMAGES ? AF_S * SLOT : IMAGES);
+  // the four 4-KiB strips of the norm prologue: ring slot 2 when it is large enough (self: 24 KiB), else behind the ring
+  constexpr int STRIP_OFF = SLOT >= 16384 ? 2 * SLOT : AF_S * SLOT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ring = smem;  // AF_S slots of the weight stream; later the attention images
   const AttnMP& p = f.a;
@@ -269,50 +270,66 @@ __global__ __launch_bounds__(256, 2) void t5_attn_fused_fwd(AttnFusedP f) {
                                        (__attribute__((address_space(3))) void*)(st + (wave * LPW + i) * 1024), 16, 0, 0);
   };
   if (!(f.ablate & 2)) { issue(0); issue(1); }
-  // the norm weight goes through LDS (2 KiB behind the ring): read from memory inside the fragment loop below, hipcc waited for
-  // every pair of loads before issuing the next one -- sixteen L2 round trips in a row per wave, ~10 us of a 30 us kernel
-  float* gs = reinterpret_cast<float*>(smem + GAMMA_OFF);
-  *reinterpret_cast<f32x2*>(gs + tid * 2) = *reinterpret_cast<const f32x2*>(f.gamma + tid * 2);
-
-  // 1. T5LayerNorm straight into MFMA fragments: lane (row 16 wave + (lane & 15), g = lane >> 4) owns columns 32 ks + 8 g .. + 7
-  //    of its row for ks = 0 .. 15 -- the B-operand fragments of the projection -- so the normalised rows never pass through LDS
-  //    (a first form staged them in a 64 KiB image: one workgroup per CU, 60 us per launch against 41 us for the three launches).
-  //    Sum of squares: in-lane over the 128 values, then over the four lanes of the row (two shuffles).
+  // 1. T5LayerNorm into MFMA fragments.  A wave reads its 16 rows as whole rows -- two fully coalesced 1-KiB loads per row, lane l
+  //    holding columns 4 l .. + 3 and 256 + 4 l .. + 3 (loading each lane's fragment columns directly made every load touch
+  //    half-lines of 16 rows: +5 us per launch) --, reduces the sum of squares per row across the wave, and passes the normalised
+  //    bf16 rows, four rows at a time, through a 4-KiB wave-private LDS strip into the projection's B-operand layout: lane
+  //    (row 16 wave + (lane & 15), g = lane >> 4) ends up with columns 32 ks + 8 g .. + 7 for ks = 0 .. 15.  The strips live
+  //    in ring slot 2 (self) / behind the ring (cross), which the weight stream does not touch before the first barrier below.
   const int xr = wave * 16 + (lane & 15);
   const bool xvalid = xr < Lq;
   const long xrow = (long)b * Lq + (xvalid ? xr : Lq - 1);
   bf16x8 xf[NKS];
   {
-    const float* xp = f.x + xrow * D + g * 8;
-    float ss = 0.f;
-    f32x4 raw[NKS][2];
+    char* strip = smem + STRIP_OFF + wave * 4096;
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(f.gamma + lane * 4), g1 = *reinterpret_cast<const f32x4*>(f.gamma + 256 + lane * 4);
+    f32x4 v0[16], v1[16];
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-      raw[ks][0] = *reinterpret_cast<const f32x4*>(xp + ks * 32);
-      raw[ks][1] = *reinterpret_cast<const f32x4*>(xp + ks * 32 + 4);
+    for (int i = 0; i < 16; ++i) {
+      const int r = wave * 16 + i;
+      const long grow = (long)b * Lq + (r < Lq ? r : Lq - 1);  // clamped: rows past the sequence are zeroed below
+      v0[i] = *reinterpret_cast<const f32x4*>(f.x + grow * D + lane * 4);
+      v1[i] = *reinterpret_cast<const f32x4*>(f.x + grow * D + 256 + lane * 4);
+    }
+    float rsv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float ss = v0[i][0] * v0[i][0] + v0[i][1] * v0[i][1] + v0[i][2] * v0[i][2] + v0[i][3] * v0[i][3];
+      ss += v1[i][0] * v1[i][0] + v1[i][1] * v1[i][1] + v1[i][2] * v1[i][2] + v1[i][3] * v1[i][3];
+      ss = wave_sum(ss);
+      rsv[i] = (wave * 16 + i < Lq) ? rsqrtf(ss / (float)D + f.eps) : 0.f;  // rows past the sequence project to zero
     }
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks)
+    for (int bt = 0; bt < 4; ++bt) {  // four rows per pass through the strip
 #pragma unroll
-      for (int u = 0; u < 4; ++u) ss += raw[ks][0][u] * raw[ks][0][u] + raw[ks][1][u] * raw[ks][1][u];
-    ss += __shfl_xor(ss, 16, 64);
-    ss += __shfl_xor(ss, 32, 64);
-    const float rs = xvalid ? rsqrtf(ss / (float)D + f.eps) : 0.f;  // rows past the sequence project to zero
-    __syncthreads();  // the norm weight is in LDS (the fence also waits for the row loads, which are needed here anyway)
-    const float* gp = gs + g * 8;
+      for (int ii = 0; ii < 4; ++ii) {
+        const int i = bt * 4 + ii;
+        const float rs = rsv[i];
+        const bf16x4 o0 = bf16x4{(bf16_t)(g0[0] * (v0[i][0] * rs)), (bf16_t)(g0[1] * (v0[i][1] * rs)), (bf16_t)(g0[2] * (v0[i][2] * rs)), (bf16_t)(g0[3] * (v0[i][3] * rs))};
+        const bf16x4 o1 = bf16x4{(bf16_t)(g1[0] * (v1[i][0] * rs)), (bf16_t)(g1[1] * (v1[i][1] * rs)), (bf16_t)(g1[2] * (v1[i][2] * rs)), (bf16_t)(g1[3] * (v1[i][3] * rs))};
+        // strip row ii (1 KiB): 16-byte chunk c at position c ^ (ii << 2) (the four rows a read touches land in different
+        // 64-byte groups of the bank row); columns 4 l .. + 3 = half (l & 1) of chunk l >> 1
+        *reinterpret_cast<bf16x4*>(strip + ii * 1024 + (((lane >> 1) ^ (ii << 2)) * 16) + (lane & 1) * 8) = o0;
+        *reinterpret_cast<bf16x4*>(strip + ii * 1024 + (((32 + (lane >> 1)) ^ (ii << 2)) * 16) + (lane & 1) * 8) = o1;
+        if (h == 0 && wave * 16 + i < Lq) {  // what the backward pass reads: normalised rows + 1/rms, once per sample
+          const long grow = (long)b * Lq + wave * 16 + i;
+          *reinterpret_cast<bf16x4*>(f.xn + grow * D + lane * 4) = o0;
+          *reinterpret_cast<bf16x4*>(f.xn + grow * D + 256 + lane * 4) = o1;
+          if (lane == 0) f.rstd[grow] = rs;
+        }
+      }
+      // the lanes whose row is in this pass pick up their 16 fragments (wave-private strip, LDS operations of a wave are in order)
+      const int ii = (lane & 15) - bt * 4;
+      if (ii >= 0 && ii < 4) {
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp + ks * 32), g1 = *reinterpret_cast<const f32x4*>(gp + ks * 32 + 4);
-      const f32x4 a0 = raw[ks][0], a1 = raw[ks][1];
-      xf[ks] = bf16x8{(bf16_t)(g0[0] * (a0[0] * rs)), (bf16_t)(g0[1] * (a0[1] * rs)), (bf16_t)(g0[2] * (a0[2] * rs)), (bf16_t)(g0[3] * (a0[3] * rs)),
-                      (bf16_t)(g1[0] * (a1[0] * rs)), (bf16_t)(g1[1] * (a1[1] * rs)), (bf16_t)(g1[2] * (a1[2] * rs)), (bf16_t)(g1[3] * (a1[3] * rs))};
-    }
-    if (h == 0 && xvalid) {  // what the backward pass reads: normalised rows + 1/rms, written once per sample (by its head-0 workgroup)
-#pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) *reinterpret_cast<bf16x8*>(f.xn + xrow * D + ks * 32 + g * 8) = xf[ks];
-      if (g == 0) f.rstd[xrow] = rs;
+        for (int ks = 0; ks < NKS; ++ks)
+          xf[ks] = *reinterpret_cast<const bf16x8*>(strip + ii * 1024 + (((4 * ks + g) ^ (ii << 2)) * 16));
+      }
     }
   }
+
+  // (the strip reads have returned before any wave can pass the first barrier below and refill ring slot 2)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
   // 2. projection: acc[j][r] = out[row 16 wave + (lane & 15)][column 16 j + 4 g + r]
   f32x4 acc[NJ];
@@ -1412,7 +1429,9 @@ int t5_attn_fused_fwd_dispatch(const klab_attn_fused_args* fa, hipStream_t s) {
   f.ablate = abl;
   const size_t images = 3 * (size_t)64 * (AF_DK * 2 + 16) + TrImg<AF_DK>::bytes(64);
   const size_t ring = (size_t)AF_S * (fa->cross ? 64 : 192) * 128;
-  const size_t lds = (ring > images ? ring : images) + AF_D * 4;  // + the norm weight
+  const size_t strips = fa->cross ? ring + 16384 : 0;  // (cross: the norm prologue's strips sit behind the small ring)
+  size_t lds = ring > images ? ring : images;
+  if (strips > lds) lds = strips;
   int rc;
   if (fa->cross) {
     rc = set_lds_attr(t5_attn_fused_fwd<true>, lds); if (rc) return rc;
