@@ -66,6 +66,10 @@ typedef struct klab_gemm_args {
                     float atomics (summation order, hence the last bits, then vary run to run) */
 } klab_gemm_args;
 int klab_gemm(const klab_gemm_args* args, void* stream);
+/* measurement only: HIP events around every klab_gemm launch (on the stream it is launched on) while enabled; read returns the launch
+ * count, the summed duration and the summed algorithmic FLOPs (2 M N K) since it was enabled.  Call read after a synchronize.          */
+int klab_gemm_probe_enable(int on);
+int klab_gemm_probe_read(int* launches, float* total_ms, double* flops_total);
 /* fp8 forward GEMM (BASELINE configs[4]): C = epilogue(alpha * sa[m] * sb[n * b_scale_stride] * sum_k A8(m,k) B8(n,k)).
  * A, B: OCP e4m3 bytes, both K-major (lda / ldb in bytes = elements); a_row_scale [M] and b_row_scale are the per-row
  * dequantisation scales klab_quant_fp8_rows / klab_quant_fp8_arena produce (amax / 448).  Every other field of klab_gemm_args
@@ -313,6 +317,12 @@ int klab_swin_proj_ln_fused(const void* x, const float* shortcut, const void* w,
 int klab_swin_mlp_fused(const void* x, const float* shortcut, const void* w1, const float* b1, const void* w2, const float* b2,
                         const float* gamma, const float* beta, float* out, void* outt, int dtype, int M, int C, float eps,
                         void* stream);
+/* Frozen-tower fusion of the patch embedding, HF/swinv2:234-259, 281, 293-302: out = LayerNorm(Conv2d(3 -> C, k 4, s 4)(pixels)) in one
+ * launch (no column matrix, no stored GEMM output).  w: bf16 [C, ldw >= 64], columns 48..63 zero (the Conv2d weight [C,3,4,4] flattened
+ * and zero-padded); out [B*(image_size/4)^2, C] f32, outt the same in bf16 (optional).  bf16, patch 4, 3 channels, C in {64, 96, 128};
+ * otherwise KLAB_ERR_UNSUPPORTED (caller: klab_im2col_patch_ld + klab_gemm + klab_layernorm_fwd).                                 */
+int klab_swin_patch_embed_fused(const float* pixels, const void* w, int ldw, const float* bias, const float* gamma, const float* beta,
+                                float* out, void* outt, int dtype, int B, int in_ch, int image_size, int patch, int C, float eps, void* stream);
 int klab_swin_cpb_bias_bwd(const float* dbias, const float* bias, const int* index, const float* coords, const float* hidden,
                            const float* w0, const float* w2, float* dtable, float* dw0, float* db0, float* dw2, int ntab, int n,
                            int heads, int nhidden, void* stream);

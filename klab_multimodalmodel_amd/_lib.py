@@ -54,6 +54,8 @@ class SwinAttnArgs(C.Structure):
 SIGNATURES = {
     "klab_version": [],
     "klab_gemm": [C.POINTER(GemmArgs), vp],
+    "klab_gemm_probe_enable": [i32],
+    "klab_gemm_probe_read": [vp, vp, vp],
     "klab_rmsnorm_fwd": [vp, vp, vp, i32, vp, vp, i32, i32, f32, i32, i32, i32, f32, vp, u32, vp],
     "klab_rmsnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, f32, u32, f32, u32, vp, vp],
     "klab_rmsnorm_bwd_part": [vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, f32, u32, f32, u32, vp, vp],
@@ -79,6 +81,7 @@ SIGNATURES = {
     "klab_quant_fp8_rows": [vp, i64, i32, i32, vp, i64, vp, vp],
     "klab_quant_fp8_arena": [vp, i32, i64, vp, vp, vp, vp],
     "klab_swin_qkv_attn_fused": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "klab_swin_patch_embed_fused": [vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp],
     "klab_swin_proj_ln_fused": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
     "klab_swin_attn_fwd": [C.POINTER(SwinAttnArgs), vp],
     "klab_swin_attn_bwd": [C.POINTER(SwinAttnArgs), vp],

@@ -830,8 +830,12 @@ struct WgradQueue {
   void push(const void* dy, long lddy, const void* x, long ldx, int M, int N, int K, float* dw) { q.push_back({dy, lddy, x, ldx, M, N, K, dw}); }
   int flush(const Ctx& c) {
     if (q.empty()) return 0;
-    RC(side_after_main(c));
-    Ctx cs{c.e, c.e->side, c.dt, c.es};
+    // timing diagnostics only (results are wrong / unoverlapped): KLAB_DIAG_WGRAD=skip drops the layer's weight gradients,
+    // =main runs them on the main stream behind the layer's chain instead of beside it
+    static const int diag = [] { const char* v = getenv("KLAB_DIAG_WGRAD"); return !v ? 0 : (v[0] == 's' ? 1 : (v[0] == 'm' ? 2 : 0)); }();
+    if (diag == 1) { q.clear(); return 0; }
+    if (diag != 2) RC(side_after_main(c));
+    Ctx cs{c.e, diag == 2 ? c.s : c.e->side, c.dt, c.es};
     std::vector<klab_gemm_args> gs;  // one grouped launch for the layer's weight gradients
     gs.reserve(q.size());
     for (const PendingWgrad& w : q) {
@@ -1000,6 +1004,14 @@ int swin_forward(const Ctx& c, const float* pixels, float p_in, bool refresh_bia
   // to 64 columns so that the GEMM takes the LDS-DMA path (K % 32 == 0); zeros meet zeros.
   const int Kp = e->pe_kp;
   (void)K0;
+  // frozen tower: convolution + LayerNorm in one launch straight from the pixels (no column matrix, nothing kept for a backward)
+  static const bool fused_pe = [] { const char* v = getenv("KLAB_SWIN_FUSED_EMBED"); return !v || atoi(v) != 0; }();
+  int perc = KLAB_ERR_UNSUPPORTED;
+  if (!e->cfg.train_swin && fused_pe && !e->fp8 && Kp >= 64)
+    perc = klab_swin_patch_embed_fused(pixels, woff(c, P[e->si.pew].warena_off), Kp, W[e->si.peb], W[e->si.penw], W[e->si.penb], e->x0, e->x0t, c.dt,
+                                       B, s.in_ch, s.image_size, s.patch, C0, s.ln_eps, c.ws());
+  if (perc != 0 && perc != KLAB_ERR_UNSUPPORTED) return perc;
+  if (perc != 0) {
   RC(klab_im2col_patch_ld(pixels, e->cols, c.dt, B, s.in_ch, s.image_size, s.patch, Kp, c.ws()));
   {
     klab_gemm_args g = G0(c, (int)M0, C0, Kp, e->cols, Kp, 1, woff(c, P[e->si.pew].warena_off), Kp, 1, e->pe_out, C0, c.dt);
@@ -1008,6 +1020,7 @@ int swin_forward(const Ctx& c, const float* pixels, float p_in, bool refresh_bia
   }
   RC(klab_layernorm_fwd(e->pe_out, c.dt, W[e->si.penw], W[e->si.penb], nullptr, e->x0, e->x0t, c.dt, e->pe_mean, e->pe_rstd, (int)M0, C0,
                         s.ln_eps, 0, 0, 0, 0.f, nullptr, 0, c.ws()));
+  }
   float* x = e->x0;
   void* xt = e->x0t;
   long bias_off = 0;
@@ -1377,7 +1390,15 @@ extern "C" int klab_engine_bind(klab_engine* e, int B, int Ls, int Lt, void* wor
     {  // experiment knob: KLAB_SIDE_PRIO=low|high gives the side stream (weight gradients, language encoder) another priority
       const char* pv = getenv("KLAB_SIDE_PRIO");
       int lo = 0, hi = 0;
-      if (pv && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && (pv[0] == 'l' || pv[0] == 'h'))
+      // experiment knob: KLAB_SIDE_CUS=n restricts the side stream to n of the 256 CUs (n / 8 per XCD, CU-mask bits are dealt
+      // round-robin over the XCDs) -- does confining the weight gradients to part of the chip hurt the main chain less?
+      const char* cm = getenv("KLAB_SIDE_CUS");
+      const int ncu = cm ? atoi(cm) : 0;
+      if (ncu >= 8 && ncu < 256) {
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < ncu; ++i) mask[i >> 5] |= 1u << (i & 31);
+        RC((int)hipExtStreamCreateWithCUMask(&e->side, 8, mask));
+      } else if (pv && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && (pv[0] == 'l' || pv[0] == 'h'))
         RC((int)hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, pv[0] == 'l' ? lo : hi));
       else
         RC((int)hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));

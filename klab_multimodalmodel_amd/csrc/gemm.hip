@@ -15,6 +15,7 @@
 
 #include <map>
 #include <mutex>
+#include <vector>
 
 #include "common.h"
 #include <type_traits>
@@ -1429,7 +1430,67 @@ static void fill_gemmp(const klab_gemm_args* a, GemmP& p) {
 }
 }  // namespace klab
 
+// ---- family probe (measurement only): HIP events around EVERY klab_gemm launch, on the stream it is launched on ------------
+// bench.py switches it on for a few untimed steps after the timed region and reports sum(2 M N K) / sum(duration) of the whole
+// klab_gemm family (every Linear, dgrad and wgrad of the step) beside the dominant kernel's roofline.  Off: no cost.
+namespace klab {
+struct GemmProbe {
+  std::mutex mu;
+  bool on = false;
+  std::vector<hipEvent_t> a, b;
+  std::vector<double> flops;
+  size_t n = 0;
+};
+static GemmProbe& gemm_probe() { static GemmProbe p; return p; }
+}  // namespace klab
+static int klab_gemm_impl(const klab_gemm_args* a, void* stream);
+extern "C" int klab_gemm_probe_enable(int on) {
+  klab::GemmProbe& pr = klab::gemm_probe();
+  std::lock_guard<std::mutex> lk(pr.mu);
+  if (on && pr.a.empty()) {
+    const size_t cap = 8192;
+    pr.a.assign(cap, nullptr); pr.b.assign(cap, nullptr); pr.flops.assign(cap, 0.0);
+    for (size_t i = 0; i < cap; ++i)
+      if (hipEventCreate(&pr.a[i]) != hipSuccess || hipEventCreate(&pr.b[i]) != hipSuccess) return KLAB_ERR_UNSUPPORTED;
+  }
+  pr.on = on != 0;
+  if (on) pr.n = 0;
+  return KLAB_OK;
+}
+extern "C" int klab_gemm_probe_read(int* launches, float* total_ms, double* flops_total) {
+  klab::GemmProbe& pr = klab::gemm_probe();
+  std::lock_guard<std::mutex> lk(pr.mu);
+  float tot = 0.f;
+  double fl = 0;
+  for (size_t i = 0; i < pr.n; ++i) {
+    float ms = 0.f;
+    const hipError_t er = hipEventElapsedTime(&ms, pr.a[i], pr.b[i]);
+    if (er != hipSuccess) return (int)er;
+    tot += ms;
+    fl += pr.flops[i];
+  }
+  if (launches) *launches = (int)pr.n;
+  if (total_ms) *total_ms = tot;
+  if (flops_total) *flops_total = fl;
+  return KLAB_OK;
+}
 extern "C" int klab_gemm(const klab_gemm_args* a, void* stream) {
+  klab::GemmProbe& pr = klab::gemm_probe();
+  if (!pr.on || !a) return klab_gemm_impl(a, stream);
+  size_t slot;
+  {
+    std::lock_guard<std::mutex> lk(pr.mu);
+    if (pr.n >= pr.a.size()) return klab_gemm_impl(a, stream);
+    slot = pr.n++;
+    pr.flops[slot] = 2.0 * a->M * (double)a->N * a->K;
+  }
+  hipEventRecord(pr.a[slot], (hipStream_t)stream);
+  const int rc = klab_gemm_impl(a, stream);
+  hipEventRecord(pr.b[slot], (hipStream_t)stream);
+  return rc;
+}
+
+static int klab_gemm_impl(const klab_gemm_args* a, void* stream) {
   using namespace klab;
   if (!a || !a->A || !a->B || !a->C) return KLAB_ERR_BADARG;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0) return KLAB_OK;

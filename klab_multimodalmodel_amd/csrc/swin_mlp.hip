@@ -11,6 +11,8 @@
 //   fc2, operands swapped:  D2[c][m] = sum_n W2[c][n] h[m][n]      -> a lane holds 4 consecutive channels c of row m
 //   LayerNorm over c: in-lane + two cross-lane-group shuffles; residual add; fp32 + bf16 stores.
 // The weights stream through LDS in chunks of 64 hidden units (W1 rows / W2 columns) by LDS-DMA, S slots deep.
+#include <stdlib.h>
+
 #include "common.h"
 #include "klab_mm.h"
 
@@ -271,5 +273,8 @@ extern "C" int klab_swin_proj_ln_fused(const void* x, const float* shortcut, con
   MlpP p{(const bf16_t*)x, shortcut, (const bf16_t*)w, b, nullptr, nullptr, gamma, beta, out, (bf16_t*)outt, M, eps};
   if (C == 64) return launch_mlp<64, 2, true>(p, (hipStream_t)stream);
   if (C == 128) return launch_mlp<128, 2, true>(p, (hipStream_t)stream);
+  // C = 256 (stage 2 of the caption tower): opt-in experiment (KLAB_SWIN_PROJ256=1); see DESIGN for the measurement
+  static const bool p256 = [] { const char* e = getenv("KLAB_SWIN_PROJ256"); return e && atoi(e) != 0; }();
+  if (C == 256 && p256) return launch_mlp<256, 2, true>(p, (hipStream_t)stream);
   return KLAB_ERR_UNSUPPORTED;
 }

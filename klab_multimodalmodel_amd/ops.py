@@ -189,6 +189,15 @@ def t5_attn_fwd(q, k, v, ctx, lse, *, B, H, Lq, Lk, dk, bias=None, causal=False,
     L.check(lib.klab_t5_attn_fwd(C.byref(a), L.stream_ptr()), "klab_t5_attn_fwd")
 
 
+def swin_patch_embed_fused(pixels, w_padded, bias, gamma, beta, out, outt, *, patch=4, eps=1e-5):
+    """LayerNorm(Conv2d(3 -> C, k 4, s 4)(pixels)) in one launch (klab_swin_patch_embed_fused); w_padded: bf16 [C, 64], columns 48.. zero"""
+    lib = L.load()
+    B, cin, H, _ = pixels.shape
+    L.check(lib.klab_swin_patch_embed_fused(pixels.data_ptr(), w_padded.data_ptr(), w_padded.stride(0), bias.data_ptr(), gamma.data_ptr(),
+                                            beta.data_ptr(), out.data_ptr(), L.ptr(outt), L.dtype_code(w_padded.dtype), B, cin, H, patch,
+                                            out.shape[1], eps, L.stream_ptr()), "klab_swin_patch_embed_fused")
+
+
 def t5_attn_fused_fwd(x, gamma, w, xn, rstd, proj, ctx, lse, *, B, H, Lq, Lk, dk, eps=1e-6, bias=None, causal=False, cross=False, k=None, v=None,
                       ldk=None, ldv=None, drop_p=0.0, seed=None, tag=0):
     """T5LayerNorm -> q|k|v (self) / q (cross) projection -> attention in one launch (klab_t5_attn_fused_fwd); NotImplementedError

@@ -959,6 +959,30 @@ def test_swin_qkv_attn_fused_matches_two_kernel_path(ops, R, Cc, Hh, shift, w):
     assert rel_l2(out.float().cpu(), ref.float().cpu()) < 1.5e-2
 
 
+@pytest.mark.parametrize("B,HW,Cc", [(3, 224, 64), (2, 56, 96), (1, 384, 128), (5, 28, 64)])
+def test_swin_patch_embed_fused_matches_torch(ops, B, HW, Cc):
+    """Frozen-tower patch embedding in one launch == Conv2d(3 -> C, k 4, s 4) -> LayerNorm in fp32 torch (HF/swinv2:234-259, 281,
+    293-302) on bf16-rounded weights / pixels (the operands the matrix cores see), the convolution output rounded to bf16 before the
+    norm as the three-launch path stores it."""
+    g = torch.Generator().manual_seed(3)
+    pix = torch.randn(B, 3, HW, HW, generator=g)
+    w = torch.randn(Cc, 3, 4, 4, generator=g) * 0.1
+    bias, gamma, beta = torch.randn(Cc, generator=g) * 0.1, 1 + 0.2 * torch.randn(Cc, generator=g), 0.1 * torch.randn(Cc, generator=g)
+    wp = torch.zeros(Cc, 64, dtype=torch.bfloat16)
+    wp[:, :48] = w.reshape(Cc, 48).to(torch.bfloat16)
+    conv = F.conv2d(pix.to(torch.bfloat16).float(), w.to(torch.bfloat16).float(), bias, stride=4)  # [B, C, R, R]
+    y = conv.flatten(2).transpose(1, 2).reshape(-1, Cc).to(torch.bfloat16).float()
+    ref = F.layer_norm(y, (Cc,), gamma, beta, 1e-5)
+    R = HW // 4
+    out = torch.zeros(B * R * R, Cc, device="cuda")
+    outt = torch.zeros(B * R * R, Cc, device="cuda", dtype=torch.bfloat16)
+    ops.swin_patch_embed_fused(dev(pix), dev(wp), dev(bias), dev(gamma), dev(beta), out, outt)
+    assert rel_l2(out.cpu(), ref) < 4e-3, rel_l2(out.cpu(), ref)  # (a bf16 rounding flip of the conv output moves a normalised value by ~0.4 %)
+    assert rel_l2(outt.float().cpu(), ref) < 6e-3
+    with pytest.raises(NotImplementedError):
+        ops.swin_patch_embed_fused(dev(pix), dev(wp), dev(bias), dev(gamma), dev(beta), out, outt, patch=2)
+
+
 def test_error_paths_of_the_entry_points_added_in_round_two(ops):
     """bad arguments and unsupported shapes come back as KLAB_ERR_* (ValueError / NotImplementedError), never as a launch"""
     import ctypes as C
