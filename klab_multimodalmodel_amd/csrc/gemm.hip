@@ -921,8 +921,12 @@ static int dispatch_tile(GemmP& p, bool atomic_ok, hipStream_t s, int p8_force =
       return KLAB_OK;
     }
   }
-  if (tiles(128, 128) >= 240) return dispatch_layout<T, 128, 128>(p, false, s);
-  if (tiles(128, 64) >= 240) return dispatch_layout<T, 128, 64>(p, false, s);
+  // a grid of about one workgroup per CU or more.  224, not 240: the T5-small encoder's M = 3712 gives 29 x 8 = 232 tiles of
+  // 128 x 64, which measured 0.4 % faster per step than the 464 tiles of 64 x 64 the higher threshold chose (same box, 3 rounds:
+  // 6.135 / 6.139 / 6.167 vs 6.173 / 6.159 / 6.179 ms).  KLAB_GEMM_TILE_MIN: tuning aid.
+  static const int tmin = [] { const char* e = getenv("KLAB_GEMM_TILE_MIN"); return e ? atoi(e) : 224; }();
+  if (tiles(128, 128) >= tmin) return dispatch_layout<T, 128, 128>(p, false, s);
+  if (tiles(128, 64) >= tmin) return dispatch_layout<T, 128, 64>(p, false, s);
   if (atomic_ok && nt >= 16) {
     const bool big = p.M >= 128 && p.N >= 64;
     const long t = big ? tiles(128, 64) : tiles(64, 64);
