@@ -22,6 +22,7 @@
 #include <string>
 #include <vector>
 
+#include "gemm_shared.h"  // klab::tl_launch_probe: a launch carries the probe's events as its own start / stop events
 #include "klab_mm.h"
 
 namespace {
@@ -845,13 +846,16 @@ struct WgradQueue {
     }
     klab_engine::Probe& pr = c.e->probe[1];
     const bool probe = c.e->probe_on && pr.n < (int)pr.a.size();
-    if (probe) RC((int)hipEventRecord(pr.a[pr.n], cs.s));
+    // (the grouped launch itself carries the events as its start / stop events: no extra packets on the stream)
+    if (probe) { klab::tl_launch_probe.a = pr.a[pr.n]; klab::tl_launch_probe.b = pr.b[pr.n]; }
     RC(klab_gemm_grouped(gs.data(), (int)gs.size(), cs.ws()));
     if (probe) {
-      RC((int)hipEventRecord(pr.b[pr.n], cs.s));
-      double fl = 0;
-      for (const PendingWgrad& w : q) fl += 2.0 * w.M * (double)w.N * w.K;
-      pr.flops[pr.n++] = fl;
+      if (klab::tl_launch_probe.a) klab::tl_launch_probe.a = nullptr;  // no grouped launch happened (members went through klab_gemm)
+      else {
+        double fl = 0;
+        for (const PendingWgrad& w : q) fl += 2.0 * w.M * (double)w.N * w.K;
+        pr.flops[pr.n++] = fl;
+      }
     }
     q.clear();
     return 0;
@@ -1615,9 +1619,12 @@ extern "C" int klab_engine_forward(klab_engine* e, const float* pixels, const lo
     // the LM-head launch stays outside the graphs so that the probe's HIP events can bracket it
     klab_engine::Probe& pr = e->probe[0];
     const bool probe = e->probe_on && pr.n < (int)pr.a.size();
-    if (probe) RC((int)hipEventRecord(pr.a[pr.n], c.s));
+    if (probe) { klab::tl_launch_probe.a = pr.a[pr.n]; klab::tl_launch_probe.b = pr.b[pr.n]; }
     RC(fwd_gemm(c, g, e->P[2][e->mi.shared].warena_off));
-    if (probe) { RC((int)hipEventRecord(pr.b[pr.n], c.s)); pr.flops[pr.n++] = 2.0 * Md * (double)V * d; }
+    if (probe) {
+      if (klab::tl_launch_probe.a) klab::tl_launch_probe.a = nullptr;  // (a launch path without the hook, e.g. fp8: not recorded)
+      else pr.flops[pr.n++] = 2.0 * Md * (double)V * d;
+    }
     RC(run_graphed(e, want_grad ? 3 : 2, c.s, [&]() {
       return klab_ce_fwd(e->logits, V, c.dt, e->tgt_buf, Md, V, e->inv_n, e->loss_row, e->loss, want_grad, c.ws());
     }));

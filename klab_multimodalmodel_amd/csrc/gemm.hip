@@ -816,7 +816,7 @@ static int launch_kernel(K kern, const GemmP& p, int BM, int BN, size_t lds, hip
     if (rc) return rc;
   }
   const long tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(tm * tn * p.splits)), dim3(256), lds, s, p);
+  probed_launch(kern, dim3((unsigned)(tm * tn * p.splits)), dim3(256), lds, s, p);
   KLAB_LAUNCH_CHECK();
   return KLAB_OK;
 }
@@ -915,8 +915,8 @@ static int dispatch_tile(GemmP& p, bool atomic_ok, hipStream_t s, int p8_force =
       const void* kern = p.b_kmajor ? reinterpret_cast<const void*>(gemm_glds_w8_kernel<true>) : reinterpret_cast<const void*>(gemm_glds_w8_kernel<false>);
       const int rc = ensure_dyn_lds(kern, lds);
       if (rc) return rc;
-      if (p.b_kmajor) hipLaunchKernelGGL(gemm_glds_w8_kernel<true>, dim3((unsigned)tiles(256, 128)), dim3(512), lds, s, p);
-      else hipLaunchKernelGGL(gemm_glds_w8_kernel<false>, dim3((unsigned)tiles(256, 128)), dim3(512), lds, s, p);
+      if (p.b_kmajor) probed_launch(gemm_glds_w8_kernel<true>, dim3((unsigned)tiles(256, 128)), dim3(512), lds, s, p);
+      else probed_launch(gemm_glds_w8_kernel<false>, dim3((unsigned)tiles(256, 128)), dim3(512), lds, s, p);
       KLAB_LAUNCH_CHECK();
       return KLAB_OK;
     }
@@ -1355,8 +1355,8 @@ extern "C" int klab_gemm_grouped(const klab_gemm_args* list, int n, void* stream
     int rc = ensure_dyn_lds(wide ? reinterpret_cast<const void*>(gemm_glds_grouped_tn_kernel<128>)
                                  : reinterpret_cast<const void*>(gemm_glds_grouped_tn_kernel<64>), lds);
     if (rc) return rc;
-    if (wide) hipLaunchKernelGGL(gemm_glds_grouped_tn_kernel<128>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, g);
-    else hipLaunchKernelGGL(gemm_glds_grouped_tn_kernel<64>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, g);
+    if (wide) probed_launch(gemm_glds_grouped_tn_kernel<128>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, g);
+    else probed_launch(gemm_glds_grouped_tn_kernel<64>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, g);
     KLAB_LAUNCH_CHECK();
     g.n = 0; blocks = 0;
     return KLAB_OK;
@@ -1466,14 +1466,17 @@ extern "C" int klab_gemm_probe_read(int* launches, float* total_ms, double* flop
   std::lock_guard<std::mutex> lk(pr.mu);
   float tot = 0.f;
   double fl = 0;
+  int cnt = 0;
   for (size_t i = 0; i < pr.n; ++i) {
+    if (pr.flops[i] < 0) continue;
     float ms = 0.f;
     const hipError_t er = hipEventElapsedTime(&ms, pr.a[i], pr.b[i]);
-    if (er != hipSuccess) return (int)er;
+    if (er != hipSuccess) { (void)hipGetLastError(); continue; }
     tot += ms;
     fl += pr.flops[i];
+    ++cnt;
   }
-  if (launches) *launches = (int)pr.n;
+  if (launches) *launches = cnt;
   if (total_ms) *total_ms = tot;
   if (flops_total) *flops_total = fl;
   return KLAB_OK;
@@ -1488,9 +1491,14 @@ extern "C" int klab_gemm(const klab_gemm_args* a, void* stream) {
     slot = pr.n++;
     pr.flops[slot] = 2.0 * a->M * (double)a->N * a->K;
   }
-  hipEventRecord(pr.a[slot], (hipStream_t)stream);
+  klab::tl_launch_probe.a = pr.a[slot];  // the launch this call makes carries the pair as its start / stop events
+  klab::tl_launch_probe.b = pr.b[slot];
   const int rc = klab_gemm_impl(a, stream);
-  hipEventRecord(pr.b[slot], (hipStream_t)stream);
+  if (klab::tl_launch_probe.a) {  // no tile kernel was launched (empty product, a path outside the family): the slot stays empty
+    klab::tl_launch_probe.a = nullptr;
+    std::lock_guard<std::mutex> lk(pr.mu);
+    pr.flops[slot] = -1.0;
+  }
   return rc;
 }
 

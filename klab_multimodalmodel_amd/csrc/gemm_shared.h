@@ -6,7 +6,24 @@
 #include <type_traits>
 #include <utility>
 
+#include <hip/hip_ext.h>
+
 namespace klab {
+
+// Measurement hook of the family probe (klab_gemm_probe_*): when the calling thread has armed a pair of events, the NEXT tile-kernel
+// launch carries them as its own start / stop events (hipExtLaunchKernelGGL: the dispatch's begin / end timestamps, no extra
+// packets on the stream -- a hipEventRecord pair around a launch added several microseconds of barrier handling per kernel).
+struct LaunchProbe { hipEvent_t a = nullptr, b = nullptr; };
+inline thread_local LaunchProbe tl_launch_probe;
+template <typename K, typename... Args>
+inline void probed_launch(K kern, dim3 grid, dim3 block, size_t lds, hipStream_t s, Args... args) {
+  if (tl_launch_probe.a) {
+    hipExtLaunchKernelGGL(kern, grid, block, (unsigned)lds, s, tl_launch_probe.a, tl_launch_probe.b, 0, args...);
+    tl_launch_probe.a = nullptr;
+  } else {
+    hipLaunchKernelGGL(kern, grid, block, lds, s, args...);
+  }
+}
 
 struct GemmP {
   int M, N, K;

@@ -553,7 +553,7 @@ int mm8p_try(const GemmP& pin, bool atomic_ok, int force, hipStream_t s) {
   {                                                                                                     \
     rc = ensure_dyn_lds(reinterpret_cast<const void*>(mm8p_kernel<AKv, BKv, ATv>), lds);                \
     if (rc) return rc;                                                                                  \
-    hipLaunchKernelGGL((mm8p_kernel<AKv, BKv, ATv>), grid, dim3(NT), lds, s, p);                        \
+    probed_launch(mm8p_kernel<AKv, BKv, ATv>, grid, dim3(NT), lds, s, p);                               \
   }
   if (atomic) {
     if (p.a_kmajor && p.b_kmajor) KLAB_P8(true, true, true)
