@@ -318,6 +318,7 @@ def main():
     probes = [eng.probe_read(ch) for ch in (0, 1)]
     eng.probe_enable(False)
     lossv = float(loss.item())
+    reducer_stats = ddp.reducer.stats() if ddp is not None else None  # (of the timed steps only: the probe steps below reduce too)
     # OUTSIDE the timed region: three more steps with HIP events around every klab_gemm launch -> the whole GEMM family's
     # sum(2 M N K) / sum(duration) (every Linear / dgrad / LM-head product of the step; the grouped weight gradients are channel 1)
     family = None
@@ -366,7 +367,7 @@ def main():
                        "host_enqueue_ms_per_step": round(host_ms, 3), "final_loss": round(lossv, 4)},
         }
         if ddp is not None:  # evidence that the N > 1 path really reduced over RCCL: ranks and bytes all-reduced per step
-            st = ddp.reducer.stats()
+            st = reducer_stats
             out["config"]["rccl"] = {"ranks": dist.get_world_size(), "backend": dist.get_backend(),
                                      "allreduce_calls_per_step": round(st["calls"] / max(a.steps, 1), 2),
                                      "allreduce_bytes_per_step": int(st["bytes"] / max(a.steps, 1)),
