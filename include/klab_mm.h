@@ -323,6 +323,12 @@ int klab_swin_mlp_fused(const void* x, const float* shortcut, const void* w1, co
  * otherwise KLAB_ERR_UNSUPPORTED (caller: klab_im2col_patch_ld + klab_gemm + klab_layernorm_fwd).                                 */
 int klab_swin_patch_embed_fused(const float* pixels, const void* w, int ldw, const float* bias, const float* gamma, const float* beta,
                                 float* out, void* outt, int dtype, int B, int in_ch, int image_size, int patch, int C, float eps, void* stream);
+/* Frozen-tower fusion for the WIDE stages, HF/swinv2:496-506 / 555-563 + 697-702: out = shortcut + LayerNorm(x W^T + b) * gamma + beta in
+ * one launch, for the attention output projection (K = C) and the MLP's second Linear (K = 4C).  x [M, K], w [C, K] in `dtype` (bf16
+ * only), the rest f32; out [M, C] f32, outt its bf16 copy (optional).  C == 256, K % 32 == 0, K >= 128; otherwise
+ * KLAB_ERR_UNSUPPORTED (caller: klab_gemm + klab_layernorm_fwd).                                                                    */
+int klab_swin_linear_ln_fused(const void* x, const float* shortcut, const void* w, const float* bias, const float* gamma,
+                              const float* beta, float* out, void* outt, int dtype, int M, int K, int C, float eps, void* stream);
 int klab_swin_cpb_bias_bwd(const float* dbias, const float* bias, const int* index, const float* coords, const float* hidden,
                            const float* w0, const float* w2, float* dtable, float* dw0, float* db0, float* dw2, int ntab, int n,
                            int heads, int nhidden, void* stream);

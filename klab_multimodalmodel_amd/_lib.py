@@ -81,6 +81,7 @@ SIGNATURES = {
     "klab_quant_fp8_rows": [vp, i64, i32, i32, vp, i64, vp, vp],
     "klab_quant_fp8_arena": [vp, i32, i64, vp, vp, vp, vp],
     "klab_swin_qkv_attn_fused": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "klab_swin_linear_ln_fused": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     "klab_swin_patch_embed_fused": [vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp],
     "klab_swin_proj_ln_fused": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
     "klab_swin_attn_fwd": [C.POINTER(SwinAttnArgs), vp],

@@ -1067,6 +1067,14 @@ int swin_forward(const Ctx& c, const float* pixels, float p_in, bool refresh_bia
         prc = klab_swin_proj_ln_fused(q.ctx, x, woff(c, P[ix.pw].warena_off), W[ix.pb], W[ix.ln1w], W[ix.ln1b], q.h1, q.h1t, c.dt, M, C, s.ln_eps,
                                       c.ws());
       if (prc != 0 && prc != KLAB_ERR_UNSUPPORTED) return prc;
+      // frozen tower, wide stage (C = 256): Linear + bias + LayerNorm + residual in one launch, 64 rows x all columns per workgroup
+      static const bool fused_lin_ln = [] { const char* v = getenv("KLAB_SWIN_FUSED_LIN_LN"); return !v || atoi(v) != 0; }();
+      const bool wide_ln = !e->cfg.train_swin && !e->fp8 && fused_lin_ln;
+      if (prc != 0 && wide_ln) {
+        prc = klab_swin_linear_ln_fused(q.ctx, x, woff(c, P[ix.pw].warena_off), W[ix.pb], W[ix.ln1w], W[ix.ln1b], q.h1, q.h1t, c.dt, M, C, C,
+                                        s.ln_eps, c.ws());
+        if (prc != 0 && prc != KLAB_ERR_UNSUPPORTED) return prc;
+      }
       if (prc != 0) {
         RC(linear_fwd(c, q.ctx, M, C, P[ix.pw].warena_off, C, q.po, C, c.dt, W[ix.pb]));
         RC(ln_fwd_for_linear(c, q.po, W[ix.ln1w], W[ix.ln1b], x, q.h1, q.h1t, q.mean1, q.rstd1, M, C, s.ln_eps));
@@ -1083,8 +1091,15 @@ int swin_forward(const Ctx& c, const float* pixels, float p_in, bool refresh_bia
         if (frc != KLAB_ERR_UNSUPPORTED) return frc;
         RC(linear_fwd(c, q.h1t, M, C, P[ix.f1w].warena_off, F, q.a, F, c.dt, W[ix.f1b], KLAB_ACT_GELU));
       }
-      RC(linear_fwd(c, q.a, M, F, P[ix.f2w].warena_off, C, q.fo, C, c.dt, W[ix.f2b]));
-      RC(ln_fwd_for_linear(c, q.fo, W[ix.ln2w], W[ix.ln2b], q.h1, q.h2, q.h2t, q.mean2, q.rstd2, M, C, s.ln_eps));
+      int f2rc = KLAB_ERR_UNSUPPORTED;
+      if (wide_ln)
+        f2rc = klab_swin_linear_ln_fused(q.a, q.h1, woff(c, P[ix.f2w].warena_off), W[ix.f2b], W[ix.ln2w], W[ix.ln2b], q.h2, q.h2t, c.dt, M, F, C,
+                                         s.ln_eps, c.ws());
+      if (f2rc != 0 && f2rc != KLAB_ERR_UNSUPPORTED) return f2rc;
+      if (f2rc != 0) {
+        RC(linear_fwd(c, q.a, M, F, P[ix.f2w].warena_off, C, q.fo, C, c.dt, W[ix.f2b]));
+        RC(ln_fwd_for_linear(c, q.fo, W[ix.ln2w], W[ix.ln2b], q.h1, q.h2, q.h2t, q.mean2, q.rstd2, M, C, s.ln_eps));
+      }
       x = q.h2; xt = q.h2t;
     }
     if (st < s.n_stages - 1) {

@@ -189,6 +189,16 @@ def t5_attn_fwd(q, k, v, ctx, lse, *, B, H, Lq, Lk, dk, bias=None, causal=False,
     L.check(lib.klab_t5_attn_fwd(C.byref(a), L.stream_ptr()), "klab_t5_attn_fwd")
 
 
+def swin_linear_ln_fused(x, shortcut, w, bias, gamma, beta, out, outt=None, *, eps=1e-5):
+    """shortcut + LayerNorm(x @ w.T + bias) * gamma + beta in one launch (klab_swin_linear_ln_fused); NotImplementedError outside the
+    envelope (bf16, 256 output columns, K a multiple of 64)"""
+    lib = L.load()
+    M, K = x.shape
+    L.check(lib.klab_swin_linear_ln_fused(x.data_ptr(), shortcut.data_ptr(), w.data_ptr(), bias.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                          out.data_ptr(), L.ptr(outt), L.dtype_code(x.dtype), M, K, w.shape[0], eps, L.stream_ptr()),
+            "klab_swin_linear_ln_fused")
+
+
 def swin_patch_embed_fused(pixels, w_padded, bias, gamma, beta, out, outt, *, patch=4, eps=1e-5):
     """LayerNorm(Conv2d(3 -> C, k 4, s 4)(pixels)) in one launch (klab_swin_patch_embed_fused); w_padded: bf16 [C, 64], columns 48.. zero"""
     lib = L.load()

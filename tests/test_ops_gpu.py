@@ -983,6 +983,31 @@ def test_swin_patch_embed_fused_matches_torch(ops, B, HW, Cc):
         ops.swin_patch_embed_fused(dev(pix), dev(wp), dev(bias), dev(gamma), dev(beta), out, outt, patch=2)
 
 
+@pytest.mark.parametrize("M,K", [(12544, 256), (12544, 1024), (200, 128), (64, 256), (777, 512), (100, 160), (31, 1024)])
+def test_swin_linear_ln_fused_matches_torch(ops, M, K):
+    """Frozen-tower wide stage: shortcut + LayerNorm(x W^T + b) in one launch == fp32 torch on the bf16-rounded operands, the Linear's
+    output rounded to bf16 before the norm as the two-launch path stores it (HF/swinv2:496-506 / 555-563 + 697-702).  Ragged row
+    counts (the last workgroup's rows past M) and both call sites' K (C and 4C at C = 256) are covered."""
+    Cc = 256
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(Cc, K, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    bias, gamma, beta = torch.randn(Cc, generator=g) * 0.1, 1 + 0.2 * torch.randn(Cc, generator=g), 0.1 * torch.randn(Cc, generator=g)
+    shortcut = torch.randn(M, Cc, generator=g)
+    y = (x.float() @ w.float().T + bias).to(torch.bfloat16).float()
+    ref = shortcut + F.layer_norm(y, (Cc,), gamma, beta, 1e-5)
+    out = torch.full((M + 8, Cc), 7.0, device="cuda")  # 8 guard rows: nothing past row M may be written
+    outt = torch.full((M + 8, Cc), 7.0, device="cuda", dtype=torch.bfloat16)
+    ops.swin_linear_ln_fused(dev(x), dev(shortcut), dev(w), dev(bias), dev(gamma), dev(beta), out[:M], outt[:M])
+    assert rel_l2(out[:M].cpu(), ref) < 3e-3, rel_l2(out[:M].cpu(), ref)  # (bf16 rounding flips of the Linear's output)
+    assert rel_l2(outt[:M].float().cpu(), ref) < 5e-3
+    assert torch.equal(outt[:M].cpu(), out[:M].to(torch.bfloat16).cpu())
+    assert bool((out[M:] == 7.0).all()) and bool((outt[M:] == 7.0).all())
+    with pytest.raises(NotImplementedError):  # widths other than 256 stay on the two-launch path
+        ops.swin_linear_ln_fused(dev(x), dev(shortcut[:, :128].contiguous()), dev(w[:128].contiguous()), dev(bias[:128]), dev(gamma[:128]),
+                                 dev(beta[:128]), out[:M, :128].contiguous(), None)
+
+
 def test_error_paths_of_the_entry_points_added_in_round_two(ops):
     """bad arguments and unsupported shapes come back as KLAB_ERR_* (ValueError / NotImplementedError), never as a launch"""
     import ctypes as C
