@@ -437,6 +437,10 @@ int klab_engine_backward(klab_engine* e, int segment, const float* dloss_dev, vo
 int klab_engine_probe_enable(klab_engine* e, int on);
 int klab_engine_probe_read(klab_engine* e, int channel, int* launches, float* total_ms, double* flops_total);
 const float* klab_engine_loss_ptr(const klab_engine* e);
+/* One-shot: the NEXT klab_engine_forward writes its mean loss to `out` (a device float owned by the caller) instead of the engine's
+ * slot -- a caller that hands out a fresh tensor per step (MyModel.forward, ref/models/model.py:26) then needs no copy launch behind
+ * the cross-entropy.  Returns 1 if it will be honoured, 0 under graph replay (the loss stays at klab_engine_loss_ptr), < 0 on error. */
+int klab_engine_set_loss_out(klab_engine* e, float* out);
 const int* klab_engine_err_ptr(const klab_engine* e);
 /* device words {seed of the current step, base seed, forwards since seeding} (for stream-ordered snapshots; see klab_engine_get_rng) */
 const uint32_t* klab_engine_rng_ptr(const klab_engine* e);

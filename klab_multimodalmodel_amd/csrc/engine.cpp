@@ -154,6 +154,13 @@ struct klab_engine {
   // side stream: independent chains run beside the main one (frozen language encoder || Swin; weight gradients ||
   // the activation-gradient chain); joined back with events before anything the caller can observe
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // backward entry: the gradient slices of segments 0 and 1 and the two attention-bias accumulators are cleared on the SIDE stream
+  // (behind one main->side event) while the LM-head input gradient runs; the main stream waits for ev_zero before its first use
+  hipEvent_t ev_zero = nullptr;
+  bool seg1_zeroed = false;      // segment 1's slice is clear and nothing has written it since
+  bool dbias_zeroed[2] = {false, false};  // [decoder stack, encoder stack]
+  bool denc_in_dxn = false;      // segment 0 left d(encoder output) in dxn, where segment 1's stack reads it
+  float* loss_out = nullptr;     // one-shot destination of the next forward's loss (klab_engine_set_loss_out)
   // stream capture is illegal on the legacy default stream (where PyTorch runs unless told otherwise): in graph mode
   // calls arriving on stream 0 are executed on this engine-owned stream, fenced in and out with events
   hipStream_t own = nullptr; hipEvent_t ev_in = nullptr, ev_out = nullptr;
@@ -894,7 +901,8 @@ int t5_stack_backward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Pa
     return klab_rmsnorm_bwd(dyin, x, w, rstd, dres, dx, dxt, c.dt, G(pidx), M, d, 0, 0, 0, p_y, tag_y, p_prev, tag_prev, e->seed_dev, c.ws());
   };
   auto next_dy = [&]() { return e->dy_pool[dy_i++ % e->dy_pool.size()]; };
-  RC(hipMemsetAsync(s.dbias, 0, (size_t)H * Lq * Lq * 4, c.s));
+  if (e->dbias_zeroed[stk]) e->dbias_zeroed[stk] = false;  // cleared on the side stream at backward entry
+  else RC(hipMemsetAsync(s.dbias, 0, (size_t)H * Lq * Lq * 4, c.s));
   // final norm: y = drop(norm(h[j])); previous sub-layer output dropout = FFN_OUT of the last layer
   void* dy = next_dy();  // masked, compute-dtype gradient of the current sub-layer's GEMM output
   RC(rms_bwd(e->dxn, s.h[j], W[final_ln], s.rstd_f, nullptr, dh_cur, dy, final_ln, p, tag_of(stack_id, 0, SITE_FINAL), p,
@@ -1161,6 +1169,7 @@ extern "C" void klab_engine_destroy(klab_engine* e) {
   for (auto& g : e->gs) if (g.exec) { hipGraphExecDestroy(g.exec); g.exec = nullptr; }
   if (e->ev_fork) hipEventDestroy(e->ev_fork);
   if (e->ev_join) hipEventDestroy(e->ev_join);
+  if (e->ev_zero) hipEventDestroy(e->ev_zero);
   if (e->ev_in) hipEventDestroy(e->ev_in);
   if (e->ev_out) hipEventDestroy(e->ev_out);
   for (auto ev : e->evpool) if (ev) hipEventDestroy(ev);
@@ -1424,6 +1433,7 @@ extern "C" int klab_engine_bind(klab_engine* e, int B, int Ls, int Lt, void* wor
     }
     RC((int)hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     RC((int)hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+    RC((int)hipEventCreateWithFlags(&e->ev_zero, hipEventDisableTiming));
     RC((int)hipStreamCreateWithFlags(&e->own, hipStreamNonBlocking));
     e->evpool.resize(256);
     for (auto& ev : e->evpool) RC((int)hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -1640,8 +1650,10 @@ extern "C" int klab_engine_forward(klab_engine* e, const float* pixels, const lo
       if (klab::tl_launch_probe.a) klab::tl_launch_probe.a = nullptr;  // (a launch path without the hook, e.g. fp8: not recorded)
       else pr.flops[pr.n++] = 2.0 * Md * (double)V * d;
     }
+    float* loss_dst = e->loss_out && !e->use_graph ? e->loss_out : e->loss;  // (replayed graphs write the fixed address)
+    e->loss_out = nullptr;
     RC(run_graphed(e, want_grad ? 3 : 2, c.s, [&]() {
-      return klab_ce_fwd(e->logits, V, c.dt, e->tgt_buf, Md, V, e->inv_n, e->loss_row, e->loss, want_grad, c.ws());
+      return klab_ce_fwd(e->logits, V, c.dt, e->tgt_buf, Md, V, e->inv_n, e->loss_row, loss_dst, want_grad, c.ws());
     }));
   }
   return leave_stream(e, (hipStream_t)stream, xs);
@@ -1680,6 +1692,14 @@ extern "C" int klab_engine_probe_read(klab_engine* e, int channel, int* launches
   return 0;
 }
 extern "C" const float* klab_engine_loss_ptr(const klab_engine* e) { return e ? e->loss : nullptr; }
+// One-shot: the NEXT forward writes its mean loss to `out` (a device float the caller owns) instead of the engine's slot, so that a
+// caller who must hand out a fresh tensor per step needs no copy launch behind the cross-entropy.  Ignored under graph replay
+// (klab_engine_set_graph), where the loss stays at klab_engine_loss_ptr; returns 1 if it will be honoured, 0 if not.
+extern "C" int klab_engine_set_loss_out(klab_engine* e, float* out) {
+  if (!e) return KLAB_ERR_BADARG;
+  e->loss_out = e->use_graph ? nullptr : out;
+  return e->loss_out ? 1 : 0;
+}
 extern "C" const int* klab_engine_err_ptr(const klab_engine* e) { return e ? e->err_dev : nullptr; }
 extern "C" const uint32_t* klab_engine_rng_ptr(const klab_engine* e) { return e ? e->seed_dev : nullptr; }
 
@@ -1767,16 +1787,32 @@ static int backward_segment(klab_engine* e, int segment, const float* dloss_dev,
   e->bucket_ev_live[segment] = false;
   if (segment == 0) {
     e->ev_next = 0;
-    RC((int)hipMemsetAsync(Gm + e->seg_off[0], 0, (size_t)e->seg_len[0] * 4, c.s));
     const int Md = B * e->Lt, V = cfg.main.vocab;
     const float alpha = cfg.main.scale_decoder_outputs ? 1.f / sqrtf((float)d) : 1.f;
     Ctx cs{e, e->side, c.dt, c.es};
+    // Clearing 242 MB of gradient slices and the bias accumulators took 36 + 12 us of the main chain (four fills in front of the
+    // kernels that need none of them).  They now run on the side stream, beside the LM-head input gradient; KLAB_ZERO_ON_SIDE=0:
+    // the old order.
+    static const bool zero_side = [] { const char* v = getenv("KLAB_ZERO_ON_SIDE"); return !v || atoi(v) != 0; }();
+    const bool zside = zero_side && !e->use_graph;  // (host-side flags below: not for a captured sequence)
+    if (zside) {
+      RC(side_after_main(c));  // behind every earlier reader of the gradient buffers on the caller's stream (optimizer, running sums)
+      RC((int)hipMemsetAsync(Gm + e->seg_off[0], 0, (size_t)e->seg_len[0] * 4, e->side));
+      RC((int)hipMemsetAsync(Gm + e->seg_off[1], 0, (size_t)e->seg_len[1] * 4, e->side));
+      RC((int)hipMemsetAsync(e->dec.dbias, 0, (size_t)cfg.main.n_heads * e->Lt * e->Lt * 4, e->side));
+      RC((int)hipMemsetAsync(e->enc.dbias, 0, (size_t)cfg.main.n_heads * e->Le * e->Le * 4, e->side));
+      RC((int)hipEventRecord(e->ev_zero, e->side));
+      e->seg1_zeroed = e->dbias_zeroed[0] = e->dbias_zeroed[1] = true;
+    } else {
+      RC((int)hipMemsetAsync(Gm + e->seg_off[0], 0, (size_t)e->seg_len[0] * 4, c.s));
+    }
     {  // d(dec_out) [Md,d] = dlogits [Md,V] @ shared [V,d]: K = vocabulary over only Md*d outputs => split-K, f32 atomics
       RC((int)hipMemsetAsync(e->dxn, 0, (size_t)Md * d * 4, c.s));
       klab_gemm_args g = G0(c, Md, d, V, e->logits, V, 1, woff(c, e->P[2][e->mi.shared].warena_off), d, 0, e->dxn, d, KLAB_F32);
       g.alpha = alpha; g.alpha_dev = dloss_dev; g.accumulate = 1; g.atomic_ok = 1;
       RC(klab_gemm(&g, c.ws()));
     }
+    if (zside) RC((int)hipStreamWaitEvent(c.s, e->ev_zero, 0));  // (long since signalled: the fills take a fifth of that GEMM's time)
     // the weight gradient trails BEHIND the dgrad on the side stream (run side by side the two chip-filling GEMMs took
     // longer than one after the other); it then overlaps the decoder's first, latency-bound backward kernels
     RC(side_after_main(c));
@@ -1796,15 +1832,19 @@ static int backward_segment(klab_engine* e, int segment, const float* dloss_dev,
     // cross-attention K/V projections of all layers at once: weights (side) + d(encoder output) (main)
     const int Me = B * e->Le, Nkv = nld * 2 * inner;
     RC(linear_wgrad(cs, e->dkv_all, Nkv, e->enc.out_t, d, Me, Nkv, d, Gm + e->kvall_g_off));
-    RC(linear_dgrad(c, e->dkv_all, Nkv, Me, Nkv, e->kvall_w_off, d, e->denc, KLAB_F32));
+    // d(encoder output) goes straight to dxn, where segment 1's stack reads d(final-norm output): no copy at the segment boundary
+    e->denc_in_dxn = !e->use_graph;
+    RC(linear_dgrad(c, e->dkv_all, Nkv, Me, Nkv, e->kvall_w_off, d, e->denc_in_dxn ? e->dxn : e->denc, KLAB_F32));
     return main_after_side(c);  // the segment's gradient slice is final for the caller's stream
   }
   if (segment == 1) {
     e->ev_next = 0;
-    RC((int)hipMemsetAsync(Gm + e->seg_off[1], 0, (size_t)e->seg_len[1] * 4, c.s));
+    if (e->seg1_zeroed) e->seg1_zeroed = false;  // cleared at the entry of segment 0, beside the LM-head input gradient
+    else RC((int)hipMemsetAsync(Gm + e->seg_off[1], 0, (size_t)e->seg_len[1] * 4, c.s));
     // the stack consumes dxn as d(final-norm output)
     const int Me = B * e->Le;
-    RC((int)hipMemcpyAsync(e->dxn, e->denc, (size_t)Me * d * 4, hipMemcpyDeviceToDevice, c.s));
+    if (e->denc_in_dxn) e->denc_in_dxn = false;
+    else RC((int)hipMemcpyAsync(e->dxn, e->denc, (size_t)Me * d * 4, hipMemcpyDeviceToDevice, c.s));
     float* dh0 = nullptr;
     RC(t5_stack_backward(c, cfg.main, e->P[2], e->W[2], Gm, e->mi.enc, e->mi.enc_final, e->enc, false, STACK_ENC, p, B, nullptr, nullptr, 0, 0,
                          &dh0));
@@ -1824,11 +1864,13 @@ extern "C" int klab_engine_backward(klab_engine* e, int segment, const float* dl
   int erc = 0;
   const hipStream_t s = enter_stream(e, (hipStream_t)stream, erc);
   if (erc) return erc;
-  if (segment == 0) {  // d(objective)/d(loss): staged at a fixed address (1.0 when the caller passes NULL)
-    if (dloss_dev) RC((int)hipMemcpyAsync(e->dloss_buf, dloss_dev, 4, hipMemcpyDeviceToDevice, s));
+  const float* dl = e->dloss_buf;
+  if (segment == 0) {  // d(objective)/d(loss): 1.0 when the caller passes NULL; replayed graphs read it at a fixed address
+    if (dloss_dev && !e->use_graph) dl = dloss_dev;  // eager launches read the caller's scalar in place (stream-ordered)
+    else if (dloss_dev) RC((int)hipMemcpyAsync(e->dloss_buf, dloss_dev, 4, hipMemcpyDeviceToDevice, s));
     else { static const float one = 1.f; RC((int)hipMemcpyAsync(e->dloss_buf, &one, 4, hipMemcpyHostToDevice, s)); }
   }
-  RC(run_graphed(e, 4 + segment, s, [&]() { return backward_segment(e, segment, e->dloss_buf, (void*)s); }));
+  RC(run_graphed(e, 4 + segment, s, [&]() { return backward_segment(e, segment, dl, (void*)s); }));
   return leave_stream(e, (hipStream_t)stream, s);
 }
 

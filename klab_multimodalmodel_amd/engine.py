@@ -128,6 +128,7 @@ ENGINE_SIGS = {
     "klab_engine_probe_enable": ([C.c_void_p, C.c_int], C.c_int),
     "klab_engine_probe_read": ([C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_double)], C.c_int),
     "klab_engine_loss_ptr": ([C.c_void_p], C.c_void_p),
+    "klab_engine_set_loss_out": ([C.c_void_p, C.c_void_p], C.c_int),
     "klab_engine_err_ptr": ([C.c_void_p], C.c_void_p),
     "klab_engine_rng_ptr": ([C.c_void_p], C.c_void_p),
     "klab_engine_buffer": ([C.c_void_p, C.c_char_p, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_int)], C.c_void_p),
@@ -344,6 +345,13 @@ class Engine:
     def forward(self, pixels, src_ids, tgt_ids, training, seed, want_grad=True):
         L.check(self._lib.klab_engine_forward(self._h, pixels.data_ptr(), src_ids.data_ptr(), tgt_ids.data_ptr(), int(training),
                                               int(seed) & 0xFFFFFFFF, int(want_grad), L.stream_ptr()), "klab_engine_forward")
+
+    def set_loss_out(self, out):
+        """the next forward writes its loss into `out` (a 1-element fp32 device tensor) instead of loss_view; False under graph replay"""
+        rc = self._lib.klab_engine_set_loss_out(self._h, out.data_ptr() if out is not None else None)
+        if rc < 0:
+            L.check(rc, "klab_engine_set_loss_out")
+        return rc == 1
 
     def decode_step(self, t, prev_tokens):
         """decoder over position t (>= 1) only, self-attention K/V from the binding's cache; logits -> buffer("logits_step")"""

@@ -95,15 +95,22 @@ class _LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, want_grad, pixels, src, tgt, *params):
         eng = model._engine_for(pixels, src, tgt)
+        # a fresh tensor per step, written by the cross-entropy kernel itself (no copy launch behind it)
+        out = torch.empty(1, device=pixels.device, dtype=torch.float32)
+        direct_loss = eng.set_loss_out(out)
         # the engine keeps a device-side counter RNG: the base only (re)seeds it, every forward advances it
-        eng.forward(pixels, src, tgt, training=int(model.transformer.training) | (2 if model._frozen_unchanged() else 0) | (4 if model._trainable_current() else 0),
-                    seed=model._seed_base, want_grad=want_grad)
+        try:
+            eng.forward(pixels, src, tgt, training=int(model.transformer.training) | (2 if model._frozen_unchanged() else 0) | (4 if model._trainable_current() else 0),
+                        seed=model._seed_base, want_grad=want_grad)
+        except Exception:
+            eng.set_loss_out(None)  # a forward that failed before its cross-entropy must not leave the one-shot pointer armed
+            raise
         ctx.model = model
         ctx.eng = eng
         ctx.nparams = len(params)
         model._fwd_token += 1
         ctx.token = model._fwd_token
-        return eng.loss_view[0].clone()
+        return out[0] if direct_loss else eng.loss_view[0].clone()
 
     @staticmethod
     def backward(ctx, gout):
