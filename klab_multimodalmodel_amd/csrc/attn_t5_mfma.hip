@@ -17,6 +17,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "klab_mm.h"
 
@@ -865,6 +867,173 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(FlashP p) {
   }
 }
 
+// ---- Swin-V2 forms, round 3 -------------------------------------------------------------------------------------------
+// With head dim 32 a 16 x 16 score tile is two matrix instructions (S and PV) against, per lane, four scores' worth of
+// vector work: these kernels are VALU-bound (131 TFLOP/s = 5 % of the MFMA peak in round 2's form), so the round-3 forms take
+// vector instructions and exposed latency out of the per-score path:
+//   * everything in the exp2 domain: the table is multiplied by log2(e) once when it is copied to LDS, the head's logit scale
+//     too, a score is ONE fma (s * scale + table entry) and the softmax uses v_exp_f32 directly (no multiply in front);
+//   * the table address is one subtraction: the keys' codes are stored as byte offsets (code * 4), the lane keeps the address of
+//     its query's entry for code 0;
+//   * the shifted-window mask is evaluated only in windows that HAVE more than one region (last window row / column of a shifted
+//     block: 7 of 16 windows at stage 0, none in unshifted blocks) and the key-range select only in a partial last key block
+//     (n = 576 has none) -- both are workgroup-uniform branches to separately compiled loop bodies;
+//   * the next key block's K / V rows are loaded into registers before the current block is computed (the global-load latency
+//     of every block was exposed between two barriers).
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+constexpr float kLog2e = 1.4426950408889634f;
+
+// does window `win` of a shifted block see more than one mask region?  (flash_region: only positions >= R - w differ from 0)
+__device__ __forceinline__ bool flash_window_masked(const FlashP& p, int win) {
+  const int nWr = p.R / p.w;
+  return p.shift > 0 && (win / nWr == nWr - 1 || win % nWr == nWr - 1);
+}
+
+template <int DK>
+__global__ __launch_bounds__(256) void flash_fwd_swin_kernel(FlashP p) {
+  constexpr int KS = (DK + 31) / 32, DKP = KS * 32, DT = DK / 16, KPITCH = DKP * 2 + 16, CPR = DKP / 8, NCH = FKB * CPR / 256;
+  static_assert(NCH >= 1 && FKB * CPR % 256 == 0, "one or more whole 16-byte chunks per thread and operand");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Kr = smem;
+  char* Vt = Kr + FKB * KPITCH;
+  int* kcode4 = reinterpret_cast<int*>(Vt + TrImg<DKP>::bytes(FKB));  // code * 4: a byte offset into the table
+  int* kreg = kcode4 + FKB;
+  float* tab = reinterpret_cast<float*>(kreg + FKB);
+  const int Lq = p.Lq, Lk = p.Lk;
+  const int bt = blockIdx.y / p.H, h = blockIdx.y % p.H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+  const long qrow0 = (long)bt * Lq, krow0 = (long)bt * Lk;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  const bool active = q0 < Lq;
+  const int q = q0 + (lane & 15);
+  const int qc = q < Lq ? q : Lq - 1;
+  const int win = bt % p.nW;
+  const int ntab = (2 * p.w - 1) * (2 * p.w - 1);
+  for (int t = threadIdx.x; t < ntab; t += 256) tab[t] = p.btab[(long)t * p.H + h] * kLog2e;
+  int qcode, qreg;
+  flash_tok(p, win, qc, qcode, qreg);
+  const char* cbase = reinterpret_cast<const char*>(tab) + (qcode + 2 * p.w * (p.w - 1)) * 4;
+  const bool masked = flash_window_masked(p, win);
+  bf16x8 qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int c = ks * 32 + g * 8;
+    bf16x8 v = {};
+    if (c < DK) v = *reinterpret_cast<const bf16x8*>(p.q + (qrow0 + qc) * p.ldq + (long)h * DK + c);
+    qf[ks] = v;
+  }
+  const float sc2 = (p.score_scale ? p.score_scale[h] : 1.f) * kLog2e;
+
+  // this thread's chunks of a streamed block: row ch / CPR, 8 elements from column (ch % CPR) * 8
+  bf16x8 kv[NCH], vv[NCH];
+  auto load_blk = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int ch = threadIdx.x + i * 256, r = ch / CPR, c = (ch % CPR) * 8;
+      bf16x8 a = {}, b = {};
+      if (k0 + r < Lk && c < DK) {
+        a = *reinterpret_cast<const bf16x8*>(p.k + (krow0 + k0 + r) * p.ldk + (long)h * DK + c);
+        b = *reinterpret_cast<const bf16x8*>(p.v + (krow0 + k0 + r) * p.ldv + (long)h * DK + c);
+      }
+      kv[i] = a; vv[i] = b;
+    }
+  };
+  auto store_blk = [&]() {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int ch = threadIdx.x + i * 256, r = ch / CPR, c = (ch % CPR) * 8;
+      *reinterpret_cast<bf16x8*>(Kr + r * KPITCH + c * 2) = kv[i];
+      *reinterpret_cast<bf16x8*>(Vt + TrImg<DKP>::off(r, c)) = vv[i];
+    }
+  };
+
+  float m = -INFINITY, l = 0.f;  // running maximum (log2 domain) and sum
+  f32x4 o[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto block = [&](int k0, auto MASKED, auto FULL) {
+    f32x4 s[4];
+    float mb = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Kr, KPITCH, t * 16, ks, lane), qf[ks], s[t], 0, 0, 0);
+      const i32x4 kc = *reinterpret_cast<const i32x4*>(kcode4 + t * 16 + g * 4);
+      i32x4 kr = {0, 0, 0, 0};
+      if constexpr (MASKED.value) kr = *reinterpret_cast<const i32x4*>(kreg + t * 16 + g * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float x = fmaf(s[t][r], sc2, *reinterpret_cast<const float*>(cbase - kc[r]));
+        if constexpr (MASKED.value) x += kr[r] != qreg ? -200.f * kLog2e : 0.f;
+        if constexpr (!FULL.value) x = k0 + t * 16 + g * 4 + r < Lk ? x : -INFINITY;
+        s[t][r] = x;
+        mb = fmaxf(mb, x);
+      }
+    }
+    mb = fmaxf(mb, __shfl_xor(mb, 16, 64));
+    mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
+    const float mn = fmaxf(m, mb);
+    const float corr = fast_exp2(m - mn);
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = fast_exp2(s[t][r] - mn);  // (window attention has no probability dropout: HF/swinv2 attention_probs_dropout_prob = 0)
+        sum += e;
+        s[t][r] = e;
+      }
+    l = l * corr + sum;
+    m = mn;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) { o[dt][0] *= corr; o[dt][1] *= corr; o[dt][2] *= corr; o[dt][3] *= corr; }
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      const bf16x8 pf = pack8(s[2 * sidx], s[2 * sidx + 1]);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DKP>(Vt, sidx * 32, dt * 16, lane), pf, o[dt], 0, 0, 0);
+    }
+  };
+  using T_ = std::integral_constant<bool, true>;
+  using F_ = std::integral_constant<bool, false>;
+
+  load_blk(0);
+  for (int k0 = 0; k0 < Lk; k0 += FKB) {
+    __syncthreads();  // every wave is past its reads of the previous block
+    store_blk();
+    if (threadIdx.x < FKB) {
+      const int kk = k0 + threadIdx.x;
+      int c = 0, r = -1;
+      if (kk < Lk) flash_tok(p, win, kk, c, r);
+      kcode4[threadIdx.x] = c * 4; kreg[threadIdx.x] = r;
+    }
+    __syncthreads();
+    if (k0 + FKB < Lk) load_blk(k0 + FKB);  // in flight underneath this block's arithmetic
+    if (!active) continue;
+    const bool full = k0 + FKB <= Lk;
+    if (masked) { if (full) block(k0, T_{}, T_{}); else block(k0, T_{}, F_{}); }
+    else { if (full) block(k0, F_{}, T_{}); else block(k0, F_{}, F_{}); }
+  }
+  if (!active) return;
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.f / l;
+  if (q < Lq) {
+    if (g == 0 && p.lse) p.lse[((long)bt * p.H + h) * Lq + q] = (m + __log2f(l)) * (1.f / kLog2e);  // natural-log units, as every consumer expects
+    const long trow = p.otok ? flash_token_row(p, bt, q) : 0;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const int d = dt * 16 + g * 4;
+      const bf16x4 ov = bf16x4{(bf16_t)(o[dt][0] * inv), (bf16_t)(o[dt][1] * inv), (bf16_t)(o[dt][2] * inv), (bf16_t)(o[dt][3] * inv)};
+      if (p.o) *reinterpret_cast<bf16x4*>(p.o + (qrow0 + q) * p.ldo + (long)h * DK + d) = ov;
+      if (p.otok && trow >= 0) *reinterpret_cast<bf16x4*>(p.otok + trow * p.ldot + (long)h * DK + d) = ov;
+    }
+  }
+}
+
 template <int DK, int BIAS>
 __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(FlashP p) {
   constexpr int KS = (DK + 31) / 32, DKP = KS * 32, DT = DK / 16, KPITCH = DKP * 2 + 16;
@@ -1019,15 +1188,19 @@ __global__ __launch_bounds__(256) void dbtab_reduce_kernel(const float* __restri
 // sequences (windows x images) and keeps the running sum of every dS element of its 16 x n strip per lane (NKB key blocks x 16
 // values); the LDS float atomics that scatter dS into the table -- 0.81 of 1.39 ms per stage-0 block when done per sequence --
 // run once per chunk.  grid = (query blocks, H * ceil(Bt / chunk)).
-template <int DK, int NKB>
+// Round 3: exp2 domain (table and logit scale carry log2(e): a score is one fma, P is one v_exp_f32 of a difference), table
+// address = one subtraction (codes stored as byte offsets), the shift mask only in windows that have more than one region
+// (uniform per sequence: two compiled forms of the key-block loop), the key / query range selects only in the instantiation for
+// window sizes that are not a multiple of 64 (FULL = false: n = 144).
+template <int DK, int NKB, bool FULL>
 __global__ __launch_bounds__(256, 2) void flash_bwd_dq_swin_kernel(FlashP p, int chunk) {
   constexpr int KS = (DK + 31) / 32, DKP = KS * 32, DT = DK / 16, KPITCH = DKP * 2 + 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Kr = smem;
   char* Vr = Kr + FKB * KPITCH;
   char* Kt = Vr + FKB * KPITCH;
-  int* kcode = reinterpret_cast<int*>(Kt + TrImg<DKP>::bytes(FKB));
-  int* kreg = kcode + FKB;
+  int* kcode4 = reinterpret_cast<int*>(Kt + TrImg<DKP>::bytes(FKB));  // code * 4: a byte offset into the table
+  int* kreg = kcode4 + FKB;
   float* tab = reinterpret_cast<float*>(kreg + FKB);
   const int ntab = (2 * p.w - 1) * (2 * p.w - 1);
   float* dtab = tab + ntab;
@@ -1038,11 +1211,14 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_swin_kernel(FlashP p, int
   const bool active = q0 < Lq;
   const int q = q0 + (lane & 15);
   const int qc = q < Lq ? q : Lq - 1;
-  for (int t = threadIdx.x; t < ntab; t += 256) tab[t] = p.btab[(long)t * p.H + h];
+  for (int t = threadIdx.x; t < ntab; t += 256) tab[t] = p.btab[(long)t * p.H + h] * kLog2e;
   for (int t = threadIdx.x; t < 4 * ntab; t += 256) dtab[t] = 0.f;
   const int qiy = qc / p.w, qix = qc - qiy * p.w;
   const int coff = qiy * (2 * p.w - 1) + qix + 2 * p.w * (p.w - 1);
-  const float sscale = p.score_scale ? p.score_scale[h] : 1.f;
+  const char* cbase = reinterpret_cast<const char*>(tab) + coff * 4;
+  const float sc2 = (p.score_scale ? p.score_scale[h] : 1.f) * kLog2e;
+  using T_ = std::integral_constant<bool, true>;
+  using F_ = std::integral_constant<bool, false>;
   float dsacc[NKB][4][4];
 #pragma unroll
   for (int kb = 0; kb < NKB; ++kb)
@@ -1074,10 +1250,11 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_swin_kernel(FlashP p, int
     }
     delta += __shfl_xor(delta, 16, 64);
     delta += __shfl_xor(delta, 32, 64);
-    const float lq = p.lse[((long)bt * p.H + h) * Lq + qc];
+    const float lq2 = p.lse[((long)bt * p.H + h) * Lq + qc] * kLog2e;
     f32x4 acc[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto key_blocks = [&](auto MASKED) {
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
       int k0 = kb * FKB;
@@ -1089,7 +1266,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_swin_kernel(FlashP p, int
         const int kk = k0 + threadIdx.x;
         int c = 0, r = -1;
         if (kk < Lk) flash_tok(p, win, kk, c, r);
-        kcode[threadIdx.x] = c; kreg[threadIdx.x] = r;
+        kcode4[threadIdx.x] = c * 4; kreg[threadIdx.x] = r;
       }
       __syncthreads();
       if (!active) continue;
@@ -1105,11 +1282,15 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_swin_kernel(FlashP p, int
             st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Kr, KPITCH, t * 16, ks, lane), qf[ks], st, 0, 0, 0);
             dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Vr, KPITCH, t * 16, ks, lane), dof[ks], dpt, 0, 0, 0);
           }
+          const i32x4 kc = *reinterpret_cast<const i32x4*>(kcode4 + t * 16 + g * 4);
+          i32x4 kr = {0, 0, 0, 0};
+          if constexpr (MASKED.value) kr = *reinterpret_cast<const i32x4*>(kreg + t * 16 + g * 4);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int kl = t * 16 + g * 4 + r, key = k0 + kl;
-            const float x = st[r] * sscale + tab[coff - kcode[kl]] + (kreg[kl] != qreg ? -200.f : 0.f);  // (branch-free, as the forward)
-            const float dsv = (key < Lk && q < Lq) ? __expf(x - lq) * (dpt[r] - delta) : 0.f;
+            float x = fmaf(st[r], sc2, *reinterpret_cast<const float*>(cbase - kc[r]));
+            if constexpr (MASKED.value) x += kr[r] != qreg ? -200.f * kLog2e : 0.f;
+            float dsv = fast_exp2(x - lq2) * (dpt[r] - delta);
+            if constexpr (!FULL) dsv = (k0 + t * 16 + g * 4 + r < Lk && q < Lq) ? dsv : 0.f;
             ds2[u][r] = dsv;
             dsacc[kb][t][r] += dsv;
           }
@@ -1119,6 +1300,8 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_swin_kernel(FlashP p, int
         for (int dt = 0; dt < DT; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DKP>(Kt, sidx * 32, dt * 16, lane), dsf, acc[dt], 0, 0, 0);
       }
     }
+    };
+    if (NKB < 9 && !flash_window_masked(p, win)) key_blocks(F_{}); else key_blocks(T_{});  // (NKB = 9: 144 running sums per lane leave no room for a second copy of the loop)
     if (active && q < Lq) {
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
@@ -1285,14 +1468,173 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(FlashP p) {
   }
 }
 
+// Swin d k / d v pass, round-3 form (see flash_fwd_swin_kernel): exp2 domain, table address = one addition on byte offsets, the
+// shift mask only in windows with more than one region, no range selects (a padded query carries LSE = +inf, i.e. P = 0; a key
+// past the end only feeds its own, never stored, output rows), and the next query block's Q / dO / O rows + LSE are loaded into
+// registers underneath the current block's arithmetic.
+template <int DK>
+__global__ __launch_bounds__(256) void flash_bwd_dkv_swin_kernel(FlashP p) {
+  constexpr int KS = (DK + 31) / 32, DKP = KS * 32, DT = DK / 16, KPITCH = DKP * 2 + 16, CPR = DKP / 8, NCH = FKB * CPR / 256;
+  static_assert(NCH >= 1 && FKB * CPR % 256 == 0, "whole 16-byte chunks per thread");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Qr = smem;
+  char* dOr = Qr + FKB * KPITCH;
+  char* Qt = dOr + FKB * KPITCH;
+  char* dOt = Qt + TrImg<DKP>::bytes(FKB);
+  float* delta = reinterpret_cast<float*>(dOt + TrImg<DKP>::bytes(FKB));
+  float* lse2 = delta + FKB;
+  int* qcode4 = reinterpret_cast<int*>(lse2 + FKB);
+  int* qreg = qcode4 + FKB;
+  float* tab = reinterpret_cast<float*>(qreg + FKB);
+  const int Lq = p.Lq, Lk = p.Lk;
+  const int bt = blockIdx.y / p.H, h = blockIdx.y % p.H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+  const long qrow0 = (long)bt * Lq, krow0 = (long)bt * Lk;
+  const int kt0 = blockIdx.x * 64 + wave * 16;
+  const bool active = kt0 < Lk;
+  const int key = kt0 + (lane & 15);
+  const int kc = key < Lk ? key : Lk - 1;
+  const int win = bt % p.nW;
+  const int ntab = (2 * p.w - 1) * (2 * p.w - 1);
+  for (int t = threadIdx.x; t < ntab; t += 256) tab[t] = p.btab[(long)t * p.H + h] * kLog2e;
+  int kcode_, kreg_;
+  flash_tok(p, win, kc, kcode_, kreg_);
+  const char* kbase = reinterpret_cast<const char*>(tab) + (2 * p.w * (p.w - 1) - kcode_) * 4;
+  const bool masked = flash_window_masked(p, win);
+  bf16x8 kf[KS], vf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int c = ks * 32 + g * 8;
+    bf16x8 a = {}, b = {};
+    if (c < DK) {
+      a = *reinterpret_cast<const bf16x8*>(p.k + (krow0 + kc) * p.ldk + (long)h * DK + c);
+      b = *reinterpret_cast<const bf16x8*>(p.v + (krow0 + kc) * p.ldv + (long)h * DK + c);
+    }
+    kf[ks] = a; vf[ks] = b;
+  }
+  const float sc2 = (p.score_scale ? p.score_scale[h] : 1.f) * kLog2e;
+  f32x4 av[DT], ak[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) { av[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; ak[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  bf16x8 vq[NCH], vd[NCH], vo[NCH];
+  float lsev[NCH];
+  auto load_blk = [&](int i0) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int ch = threadIdx.x + i * 256, r = ch / CPR, c = (ch % CPR) * 8;
+      bf16x8 a = {}, b = {}, o = {};
+      float ls = INFINITY;  // padded queries: P = exp2(-inf) = 0
+      if (i0 + r < Lq) {
+        if (c < DK) {
+          a = *reinterpret_cast<const bf16x8*>(p.q + (qrow0 + i0 + r) * p.ldq + (long)h * DK + c);
+          b = *reinterpret_cast<const bf16x8*>(p.dout + (qrow0 + i0 + r) * p.lddo + (long)h * DK + c);
+          o = *reinterpret_cast<const bf16x8*>(p.o + (qrow0 + i0 + r) * p.ldo + (long)h * DK + c);
+        }
+        if (c == 0) ls = p.lse[((long)bt * p.H + h) * Lq + i0 + r] * kLog2e;
+      }
+      vq[i] = a; vd[i] = b; vo[i] = o; lsev[i] = ls;
+    }
+  };
+  auto store_blk = [&](int i0) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int ch = threadIdx.x + i * 256, r = ch / CPR, c = (ch % CPR) * 8;
+      *reinterpret_cast<bf16x8*>(Qr + r * KPITCH + c * 2) = vq[i];
+      *reinterpret_cast<bf16x8*>(dOr + r * KPITCH + c * 2) = vd[i];
+      *reinterpret_cast<bf16x8*>(Qt + TrImg<DKP>::off(r, c)) = vq[i];
+      *reinterpret_cast<bf16x8*>(dOt + TrImg<DKP>::off(r, c)) = vd[i];
+      float a = 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += (float)vd[i][u] * (float)vo[i][u];
+#pragma unroll
+      for (int o2 = 1; o2 < CPR; o2 <<= 1) a += __shfl_xor(a, o2, 64);  // the CPR lanes of a row are neighbours
+      if (c == 0) {
+        delta[r] = a;
+        lse2[r] = lsev[i];
+        int cc = 0, rr = -1;
+        if (i0 + r < Lq) flash_tok(p, win, i0 + r, cc, rr);
+        qcode4[r] = cc * 4; qreg[r] = rr;
+      }
+    }
+  };
+  auto block = [&](auto MASKED) {
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      f32x4 pd2[2], ds2[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int qt = 2 * sidx + u;
+        f32x4 st = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Qr, KPITCH, qt * 16, ks, lane), kf[ks], st, 0, 0, 0);
+          dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(dOr, KPITCH, qt * 16, ks, lane), vf[ks], dpt, 0, 0, 0);
+        }
+        const int ql0 = qt * 16 + g * 4;
+        const i32x4 qc4 = *reinterpret_cast<const i32x4*>(qcode4 + ql0);
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse2 + ql0), d4 = *reinterpret_cast<const f32x4*>(delta + ql0);
+        i32x4 qr4 = {0, 0, 0, 0};
+        if constexpr (MASKED.value) qr4 = *reinterpret_cast<const i32x4*>(qreg + ql0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = fmaf(st[r], sc2, *reinterpret_cast<const float*>(kbase + qc4[r]));
+          if constexpr (MASKED.value) x += qr4[r] != kreg_ ? -200.f * kLog2e : 0.f;
+          const float pr = fast_exp2(x - l4[r]);
+          pd2[u][r] = pr;
+          ds2[u][r] = pr * (dpt[r] - d4[r]);
+        }
+      }
+      const bf16x8 pdf = pack8(pd2[0], pd2[1]), dsf = pack8(ds2[0], ds2[1]);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        av[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DKP>(dOt, sidx * 32, dt * 16, lane), pdf, av[dt], 0, 0, 0);
+        ak[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DKP>(Qt, sidx * 32, dt * 16, lane), dsf, ak[dt], 0, 0, 0);
+      }
+    }
+  };
+  using T_ = std::integral_constant<bool, true>;
+  using F_ = std::integral_constant<bool, false>;
+
+  load_blk(0);
+  for (int i0 = 0; i0 < Lq; i0 += FKB) {
+    __syncthreads();
+    store_blk(i0);
+    __syncthreads();
+    if (i0 + FKB < Lq) load_blk(i0 + FKB);
+    if (!active) continue;
+    if (masked) block(T_{}); else block(F_{});
+  }
+  if (active && key < Lk) {
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const int d = dt * 16 + g * 4;
+      *reinterpret_cast<bf16x4*>(p.dv + (krow0 + key) * p.lddv + (long)h * DK + d) =
+          bf16x4{(bf16_t)av[dt][0], (bf16_t)av[dt][1], (bf16_t)av[dt][2], (bf16_t)av[dt][3]};
+      *reinterpret_cast<bf16x4*>(p.dkk + (krow0 + key) * p.lddk + (long)h * DK + d) =
+          bf16x4{(bf16_t)ak[dt][0], (bf16_t)ak[dt][1], (bf16_t)ak[dt][2], (bf16_t)ak[dt][3]};
+    }
+  }
+}
+
 template <int DK, int BIAS>
 static int flash_launch(const FlashP& p, int which, hipStream_t s) {
   constexpr int KS = (DK + 31) / 32, DKP = KS * 32, KPITCH = DKP * 2 + 16;
   const size_t ntab = BIAS == 2 ? (size_t)(2 * p.w - 1) * (2 * p.w - 1) : 0;
   const size_t tr = TrImg<DKP>::bytes(FKB);
   int rc;
+  // KLAB_SWIN_FLASH_V2=0: round 2's Swin kernels (the generic streaming forms with the table look-up added)
+  static const bool v2 = [] { const char* e = getenv("KLAB_SWIN_FLASH_V2"); return !e || atoi(e) != 0; }();
   if (which == 0) {
     const size_t lds = (size_t)FKB * KPITCH + tr + 2 * FKB * 4 + ntab * 4;
+    if constexpr (BIAS == 2) {
+      if (v2) {
+        rc = ensure_dyn_lds(reinterpret_cast<const void*>(flash_fwd_swin_kernel<DK>), lds); if (rc) return rc;
+        hipLaunchKernelGGL((flash_fwd_swin_kernel<DK>), dim3((p.Lq + 63) / 64, p.Bt * p.H), dim3(256), lds, s, p);
+        KLAB_LAUNCH_CHECK();
+        return KLAB_OK;
+      }
+    }
     rc = ensure_dyn_lds(reinterpret_cast<const void*>(flash_fwd_kernel<DK, BIAS>), lds); if (rc) return rc;
     hipLaunchKernelGGL((flash_fwd_kernel<DK, BIAS>), dim3((p.Lq + 63) / 64, p.Bt * p.H), dim3(256), lds, s, p);
   } else if (which == 1) {
@@ -1301,6 +1643,14 @@ static int flash_launch(const FlashP& p, int which, hipStream_t s) {
     hipLaunchKernelGGL((flash_bwd_dq_kernel<DK, BIAS>), dim3((p.Lq + 63) / 64, p.Bt * p.H), dim3(256), lds, s, p);
   } else {
     const size_t lds = 2 * (size_t)FKB * KPITCH + 2 * tr + 4 * FKB * 4 + ntab * 4;
+    if constexpr (BIAS == 2) {
+      if (v2) {
+        rc = ensure_dyn_lds(reinterpret_cast<const void*>(flash_bwd_dkv_swin_kernel<DK>), lds); if (rc) return rc;
+        hipLaunchKernelGGL((flash_bwd_dkv_swin_kernel<DK>), dim3((p.Lk + 63) / 64, p.Bt * p.H), dim3(256), lds, s, p);
+        KLAB_LAUNCH_CHECK();
+        return KLAB_OK;
+      }
+    }
     rc = ensure_dyn_lds(reinterpret_cast<const void*>(flash_bwd_dkv_kernel<DK, BIAS>), lds); if (rc) return rc;
     hipLaunchKernelGGL((flash_bwd_dkv_kernel<DK, BIAS>), dim3((p.Lk + 63) / 64, p.Bt * p.H), dim3(256), lds, s, p);
   }
@@ -1531,9 +1881,15 @@ int swin_flash_dispatch(const void* g, long ldg, int C, void* otok, long ldot, f
     const size_t lds = 2 * (size_t)FKB * 80 + TrImg<32>::bytes(FKB) + 2 * FKB * 4 + 5 * (size_t)ntab * 4;
     int rc2 = KLAB_OK;
 #define SEQ_LAUNCH(NKB)                                                                                                  \
-    rc2 = ensure_dyn_lds(reinterpret_cast<const void*>(flash_bwd_dq_swin_kernel<32, NKB>), lds);                            \
-    if (rc2) return rc2;                                                                                                    \
-    hipLaunchKernelGGL((flash_bwd_dq_swin_kernel<32, NKB>), dim3(nqb, H * nchunks), dim3(256), lds, s, f, chunk)
+    if (n % FKB == 0) {                                                                                                     \
+      rc2 = ensure_dyn_lds(reinterpret_cast<const void*>(flash_bwd_dq_swin_kernel<32, NKB, true>), lds);                    \
+      if (rc2) return rc2;                                                                                                  \
+      hipLaunchKernelGGL((flash_bwd_dq_swin_kernel<32, NKB, true>), dim3(nqb, H * nchunks), dim3(256), lds, s, f, chunk);   \
+    } else {                                                                                                                \
+      rc2 = ensure_dyn_lds(reinterpret_cast<const void*>(flash_bwd_dq_swin_kernel<32, NKB, false>), lds);                   \
+      if (rc2) return rc2;                                                                                                  \
+      hipLaunchKernelGGL((flash_bwd_dq_swin_kernel<32, NKB, false>), dim3(nqb, H * nchunks), dim3(256), lds, s, f, chunk);  \
+    }
     if (nkb == 1) { SEQ_LAUNCH(1); } else if (nkb == 2) { SEQ_LAUNCH(2); } else if (nkb == 3) { SEQ_LAUNCH(3); } else { SEQ_LAUNCH(9); }
 #undef SEQ_LAUNCH
     KLAB_LAUNCH_CHECK();
