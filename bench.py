@@ -377,7 +377,7 @@ def main():
         # roofline of the kernels that hold the largest shares of GPU time (profiles/*_kernel_stats.csv): live HIP-event
         # durations around each launch on the stream it runs on; algorithmic FLOPs = 2*M*N*K per product
         rl = []
-        names = ["klab_lmhead_gemm<bf16> (LM-head logits GEMM [B*Lt, 32128] x d_model)",
+        names = ["klab_lmhead_areg_gemm / klab_lmhead_gemm<bf16> (LM-head logits GEMM [B*Lt, 32128] x d_model; A-stationary form at d_model 512)",
                  "gemm_glds_grouped_tn_kernel (one grouped launch = all weight-gradient GEMMs of one T5 layer, side stream)"]
         for ch, (n, tot_ms, fl) in enumerate(probes):
             if n <= 0 or tot_ms <= 0:

@@ -1502,6 +1502,7 @@ extern "C" int klab_gemm(const klab_gemm_args* a, void* stream) {
   return rc;
 }
 
+namespace klab { int lmhead_areg_try(const GemmP& p, hipStream_t s); }  // lmhead_areg.hip
 static int klab_gemm_impl(const klab_gemm_args* a, void* stream) {
   using namespace klab;
   if (!a || !a->A || !a->B || !a->C) return KLAB_ERR_BADARG;
@@ -1520,6 +1521,10 @@ static int klab_gemm_impl(const klab_gemm_args* a, void* stream) {
   if (a->name_tag == 1 && a->a_kmajor && a->b_kmajor) {
     if (a->dtype == KLAB_BF16) {
       if (a->K % 32) return KLAB_ERR_UNSUPPORTED;
+      {  // d_model = 512: the A-stationary form (A in registers, only B streams through LDS); declines everything else
+        const int rc = lmhead_areg_try(p, s);
+        if (rc != KLAB_ERR_UNSUPPORTED) return rc;
+      }
       size_t lds = KLAB_GLDS_STAGES * (size_t)(128 + 128) * 64;
       const size_t epi = (size_t)epilogue_lds_bytes<128, 128>(p.c_f32);
       return launch_kernel(klab_lmhead_gemm<bf16_t>, p, 128, 128, epi > lds ? epi : lds, s);

@@ -183,6 +183,30 @@ def test_lmhead_symbol_matches_generic_gemm(ops, dt):
     assert rel_l2(C1.float().cpu(), C2.float().cpu()) < (1e-6 if dt == torch.float32 else 4e-3)  # k-tile rotation differs with the tile shape
 
 
+@pytest.mark.parametrize("M,N", [(4096, 32128), (1024, 8192), (1100, 8200), (2048, 64 * 128 + 8)])
+def test_lmhead_a_stationary_kernel_matches_fp32(ops, M, N):
+    """d_model = 512 logits GEMM, A-stationary form (csrc/lmhead_areg.hip: A fragments in registers, B streamed through a 14-slot
+    LDS-DMA ring): every element against an fp32 product of the bf16 operands -- full BASELINE size, ragged row blocks and a ragged
+    last column tile, alpha both as a host scalar and as a device scalar (the engine passes d_model^-0.5, HF/t5:1044-1045)."""
+    K = 512
+    g = torch.Generator().manual_seed(5)
+    A = (torch.randn(M, K, generator=g)).to(torch.bfloat16)
+    B = (torch.randn(N, K, generator=g)).to(torch.bfloat16)
+    C = torch.full((M + 1, N), 3.0, device="cuda", dtype=torch.bfloat16)  # one guard row
+    ad = torch.tensor([0.5], device="cuda")
+    Ad, Bd = dev(A), dev(B)
+    ops.gemm(Ad, Bd, C[:M], M=M, N=N, K=K, alpha=K ** -0.5, alpha_dev=ad, name_tag=1)
+    ref = (Ad.float() @ Bd.float().T) * (0.5 * K ** -0.5)
+    err = (C[:M].float() - ref).abs().max().item()
+    assert err <= 2e-2 * ref.abs().max().item(), err      # bf16 rounding of the output
+    assert rel_l2(C[:M].float(), ref) < 3e-3
+    assert bool((C[M:] == 3.0).all())
+    # the same product through the tiled kernel (the A-stationary form switched off per call is not possible: compare with tag 0)
+    C0 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(Ad, Bd, C0, M=M, N=N, K=K, alpha=K ** -0.5, alpha_dev=ad)
+    assert rel_l2(C[:M].float(), C0.float()) < 3e-3
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_gemm_aux_modes_and_alpha_dev(ops, dt):
     M, N, K = 72, 48, 32
