@@ -45,7 +45,7 @@ __device__ __forceinline__ bf16x8 bfrag(const char* slot, int f, int ks, int lan
   return *reinterpret_cast<const bf16x8*>(slot + r * 128 + (((4 * ks + g) ^ (r & 7)) * 16));
 }
 
-__global__ __launch_bounds__(NTHREADS) void klab_lmhead_areg_gemm(GemmP p) {
+__global__ __launch_bounds__(NTHREADS) void klab_lmhead_areg_gemm(GemmP p, int rotate) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -60,11 +60,11 @@ __global__ __launch_bounds__(NTHREADS) void klab_lmhead_areg_gemm(GemmP p) {
   // logits stores instead.  CDNA4 counts stores in vmcnt too: with DMA and stores in the same wave every counted wait behind a
   // tile boundary also waited for that tile's stores to be acknowledged (41 us of a 199 us launch, measured by skipping them).
   // The cursor (tile, k-tile, slot) advances by one k-tile per issue: no division in the loop.
-  // The 32 row blocks of an XCD walk the same eighth of the vocabulary, each starting at a different tile of it (rotated order),
-  // so that 32 regions of the 4 MB are in flight from HBM at once and later passes over a region hit in L2.
+  // The 32 row blocks of an XCD walk the same eighth of the vocabulary in lockstep (every B line is fetched once per XCD and serves
+  // 32 workgroups); `rotate` starts each at a different tile instead (see the launch site).
   const bool dma_wave = wave < 4;
   const int srow = (wave & 3) * 32 + (lane >> 3), schunk = (lane & 7) ^ (lane >> 3);
-  const int ntl = t1 - t0, ts = t0 + rb % (ntl > 0 ? ntl : 1);
+  const int ntl = t1 - t0, ts = t0 + (rotate ? rb % (ntl > 0 ? ntl : 1) : 0);
   int is_tile = ts, is_kt = 0, is_slot = 0, issued = 0;
   const bf16_t* is_src;  // piece 0 of the current tile; pieces 1-3 are 8, 16, 24 rows further (N % 128 == 0: no row needs clamping)
   const long piece_stride = 8 * p.ldb;
@@ -189,7 +189,11 @@ int lmhead_areg_try(const GemmP& p, hipStream_t s) {
   const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(klab_lmhead_areg_gemm), (size_t)LDS_BYTES);
   if (rc) return rc;
   const unsigned grid = (unsigned)(((p.M + BM - 1) / BM) * NCHUNK);
-  probed_launch(klab_lmhead_areg_gemm, dim3(grid), dim3(NTHREADS), (size_t)LDS_BYTES, s, p);
+  // KLAB_LMHEAD_ROT=1: the row blocks of an XCD start at rotated tiles of their eighth of the vocabulary (32 regions in flight at once
+  // instead of one shared stream).  Measured the same speed, but 1.03 GB per launch leave L2 instead of ~0.35 GB (the 4 MB working set
+  // no longer survives next to the logits write stream), so the default is the lockstep walk.
+  static const int rotate = [] { const char* e = getenv("KLAB_LMHEAD_ROT"); return e ? atoi(e) : 0; }();
+  probed_launch(klab_lmhead_areg_gemm, dim3(grid), dim3(NTHREADS), (size_t)LDS_BYTES, s, p, rotate);
   KLAB_LAUNCH_CHECK();
   return KLAB_OK;
 }
