@@ -1320,6 +1320,8 @@ extern "C" int klab_engine_bind(klab_engine* e, int B, int Ls, int Lt, void* wor
     e->n_cast = n; e->cast_total4 = pre;
   }
   e->frozen_valid = false;
+  e->seg1_zeroed = e->dbias_zeroed[0] = e->dbias_zeroed[1] = e->denc_in_dxn = false;  // (hand-offs between backward segments of the OLD binding)
+  e->loss_out = nullptr;
   if (e->pe_kp != e->pe_k0)  // the padding columns of the patch-embedding weight rows: written here, never again
     RC((int)hipMemsetAsync((char*)e->warena + (size_t)e->P[0][e->si.pew].warena_off * e->es, 0,
                            (size_t)e->cfg.swin.embed_dim * e->pe_kp * e->es, hs));
