@@ -185,7 +185,8 @@ int lmhead_areg_try(const GemmP& p, hipStream_t s) {
   if (!on) return KLAB_ERR_UNSUPPORTED;
   if (p.K != K || !p.a_kmajor || !p.b_kmajor || p.c_f32 || p.accumulate || p.bias || p.act || p.aux || p.residual || p.drop_p != 0.f)
     return KLAB_ERR_UNSUPPORTED;
-  if (p.M < 1024 || p.N < 64 * BN || (p.N % BN) || (p.ldc & 7) || (p.lda & 7) || (p.ldb & 7)) return KLAB_ERR_UNSUPPORTED;
+  static const int min_n = [] { const char* e = getenv("KLAB_LMHEAD_MIN_N"); return e ? atoi(e) : 64 * BN; }();  // (tuning aid)
+  if (p.M < 1024 || p.N < min_n || (p.N % BN) || (p.ldc & 7) || (p.lda & 7) || (p.ldb & 7)) return KLAB_ERR_UNSUPPORTED;
   const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(klab_lmhead_areg_gemm), (size_t)LDS_BYTES);
   if (rc) return rc;
   const unsigned grid = (unsigned)(((p.M + BM - 1) / BM) * NCHUNK);

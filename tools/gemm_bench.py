@@ -113,7 +113,7 @@ def main():
         C = torch.zeros(M, N, device="cuda", dtype=torch.float32 if atomic else dt)
         # KLAB_BENCH_AB=1: every shape twice in this process -- the four-wave ring (name_tag 3) and the 256 x 256 eight-wave kernel
         # wherever it is legal (name_tag 2) -- interleaved rounds, median of the per-round times
-        tags = [3, 2] if os.environ.get("KLAB_BENCH_AB") == "1" else [1 if name == "lmhead fwd" else 0]
+        tags = [3, 2] if os.environ.get("KLAB_BENCH_AB") == "1" else [int(os.environ["KLAB_BENCH_TAG"])] if "KLAB_BENCH_TAG" in os.environ else [1 if name == "lmhead fwd" else 0]
         res = {}
         for rnd_ in range(3 if len(tags) > 1 else 1):
             for tag in tags:
