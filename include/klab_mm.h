@@ -332,6 +332,10 @@ int klab_swin_linear_ln_fused(const void* x, const float* shortcut, const void* 
 int klab_swin_cpb_bias_bwd(const float* dbias, const float* bias, const int* index, const float* coords, const float* hidden,
                            const float* w0, const float* w2, float* dtable, float* dw0, float* db0, float* dw2, int ntab, int n,
                            int heads, int nhidden, void* stream);
+/* the same with `dtable_zeroed`: non-zero = the caller has cleared dtable[ntab * heads] (the engine clears every block's slice in one fill) */
+int klab_swin_cpb_bias_bwd_pz(const float* dbias, const float* bias, const int* index, const float* coords, const float* hidden,
+                              const float* w0, const float* w2, float* dtable, float* dw0, float* db0, float* dw2, int ntab, int n,
+                              int heads, int nhidden, int dtable_zeroed, void* stream);
 
 /* ==== the whole path: MyModel.forward + backward (ref/models/model.py:19-26, ref/train.py:58-62) ====
  * The engine is a host-side plan over the kernels above.  It owns no device memory: parameters are

@@ -1151,14 +1151,17 @@ extern "C" int klab_swin_cpb_bias(const float* coords, const int* index, const f
   return KLAB_OK;
 }
 
-extern "C" int klab_swin_cpb_bias_bwd(const float* dbias, const float* bias, const int* index, const float* coords, const float* hidden,
-                                      const float* w0, const float* w2, float* dtable, float* dw0, float* db0, float* dw2, int ntab, int n,
-                                      int heads, int nhidden, void* stream) {
+// dtable_zeroed != 0: the caller vouches that dtable[ntab * heads] is clear (one fill for a whole tower's blocks instead of one per call)
+extern "C" int klab_swin_cpb_bias_bwd_pz(const float* dbias, const float* bias, const int* index, const float* coords, const float* hidden,
+                                         const float* w0, const float* w2, float* dtable, float* dw0, float* db0, float* dw2, int ntab, int n,
+                                         int heads, int nhidden, int dtable_zeroed, void* stream) {
   (void)w0;
   if (!dbias || !bias || !index || !coords || !hidden || !w2 || !dtable || !dw0 || !db0 || !dw2) return KLAB_ERR_BADARG;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(dtable, 0, (size_t)ntab * heads * 4, s);
-  if (e != hipSuccess) return (int)e;
+  if (!dtable_zeroed) {
+    hipError_t e = hipMemsetAsync(dtable, 0, (size_t)ntab * heads * 4, s);
+    if (e != hipSuccess) return (int)e;
+  }
   const long tot = (long)heads * n * n;
   hipLaunchKernelGGL(cpb_dtable_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, dbias, bias, index, dtable, heads, n * n);
   KLAB_LAUNCH_CHECK();
@@ -1169,6 +1172,12 @@ extern "C" int klab_swin_cpb_bias_bwd(const float* dbias, const float* bias, con
   hipLaunchKernelGGL(cpb_mlp_bwd_kernel, dim3((nhidden + 15) / 16), dim3(256), cpb_lds, s, dtable, coords, hidden, w2, dw0, db0, dw2, ntab, heads, nhidden);
   KLAB_LAUNCH_CHECK();
   return KLAB_OK;
+}
+
+extern "C" int klab_swin_cpb_bias_bwd(const float* dbias, const float* bias, const int* index, const float* coords, const float* hidden,
+                                      const float* w0, const float* w2, float* dtable, float* dw0, float* db0, float* dw2, int ntab, int n,
+                                      int heads, int nhidden, void* stream) {
+  return klab_swin_cpb_bias_bwd_pz(dbias, bias, index, coords, hidden, w0, w2, dtable, dw0, db0, dw2, ntab, n, heads, nhidden, 0, stream);
 }
 
 extern "C" int klab_swin_qkv_attn_fused(const void* x, const void* wqkv, const float* bqkv, void* ctx, const float* bias, const float* logit_scale,

@@ -146,7 +146,10 @@ struct klab_engine {
   // swin backward scratch
   float *sdh_a = nullptr, *sdh_b = nullptr, *sdm = nullptr; void *sdy = nullptr, *sdctx = nullptr, *sdqkv = nullptr, *sda = nullptr;
   void* sattn_ws = nullptr; size_t sattn_ws_bytes = 0;
+  // bias-gradient scratch of the trainable tower: ONE slice per block (dense d(bias) | d(bias table) | d(table)), cleared by a single
+  // fill at the head of swin_backward instead of two fills in front of every block's attention backward
   float *sdbias = nullptr, *sdtable = nullptr, *sdbtab = nullptr;
+  long sdb_stride = 0, sdt_stride = 0; size_t sdz_bytes = 0;
   // Swin weight gradients on the side stream: per-block gradient operands in two alternating sets (block k+2 reuses set k & 1
   // once swin_done_ev[k & 1] -- recorded on the side stream behind block k's weight gradients -- has fired)
   void *sdyA[2] = {nullptr, nullptr}, *sdyB[2] = {nullptr, nullptr}, *sdaP[2] = {nullptr, nullptr}, *sdqkvP[2] = {nullptr, nullptr};
@@ -588,9 +591,14 @@ size_t plan_workspace(klab_engine* e, void* base, int B, int Ls, int Lt) {
       if (w * w <= 64 && w * w > maxn_small) maxn_small = w * w;
       if (s.heads[st] > maxH) maxH = s.heads[st];
     }
-    e->sdbias = (float*)b.take((size_t)maxH * maxn_small * maxn_small * 4);  // dense d(bias) of the one-tile windows
-    e->sdbtab = (float*)b.take((size_t)(4 * maxn) * maxH * 4);               // d(bias table) of the large windows
-    e->sdtable = (float*)b.take((size_t)(4 * maxn) * maxH * 4 + (size_t)(4 * maxn) * 512 * 4);
+    int nblk = 0;
+    for (int st = 0; st < s.n_stages; ++st) nblk += s.depths[st];
+    e->sdb_stride = ((long)maxH * maxn_small * maxn_small + 63) & ~63L;  // dense d(bias) of the one-tile windows, floats per block
+    e->sdt_stride = ((long)(4 * maxn) * maxH + 63) & ~63L;               // d(bias table) of the large windows / d(table), floats per block
+    e->sdz_bytes = (size_t)nblk * (e->sdb_stride + 2 * e->sdt_stride) * 4;
+    e->sdbias = (float*)b.take(e->sdz_bytes);
+    e->sdbtab = e->sdbias + (long)nblk * e->sdb_stride;
+    e->sdtable = e->sdbtab + (long)nblk * e->sdt_stride;
   }
   {  // scratch of the matrix-core window attention: backward of the one-tile windows (train_swin), and forward + backward of
      // windows of more than 64 tokens (window-major copies for the streaming kernels)
@@ -1889,6 +1897,7 @@ int swin_backward(const Ctx& c, const float* dh0, float p_in) {
   auto G = [&](int pi) { return Gs + P[pi].grad_off; };
   const int B = e->B, R0 = s.image_size / s.patch, C0 = s.embed_dim;
   RC((int)hipMemsetAsync(Gs + e->seg_off[2], 0, (size_t)e->seg_len[2] * 4, c.s));
+  RC((int)hipMemsetAsync(e->sdbias, 0, e->sdz_bytes, c.s));  // every block's bias-gradient slices at once
   // final LN backward: input x = last hidden (f32), dout in the remapped encoder-input rows, with the input dropout
   const int last = s.n_stages - 1;
   const int Cl = C0 << last;
@@ -1965,18 +1974,19 @@ int swin_backward(const Ctx& c, const float* dh0, float p_in) {
       a.dctx = e->sdctx; a.dqkv = dqkv; a.dlogit_scale = G(ix.ls);
       a.bwd_ws = e->sattn_ws; a.bwd_ws_bytes = e->sattn_ws_bytes;
       if (ix.vb >= 0) { a.v_bias = e->farena + P[ix.vb].farena_off; a.dv_bias = G(ix.vb); }  // padded windows
+      float* blk_dbias = e->sdbias + blk_no * e->sdb_stride;   // this block's slices: clear since the head of swin_backward
+      float* blk_dbtab = e->sdbtab + blk_no * e->sdt_stride;
+      float* blk_dtable = e->sdtable + blk_no * e->sdt_stride;
       if (q.btab) {  // large window: the bias gradient is accumulated per table entry
-        RC((int)hipMemsetAsync(e->sdbtab, 0, (size_t)e->swin_ntab[st] * q.H * 4, c.s));
-        a.dbias_table = e->sdbtab;
+        a.dbias_table = blk_dbtab;
         RC(klab_swin_attn_bwd(&a, c.ws()));
-        RC(klab_swin_cpb_table_bwd(e->sdbtab, q.btab, e->swin_coords[st], q.hidden, W[ix.c2w], e->sdtable, G(ix.c0w), G(ix.c0b), G(ix.c2w),
+        RC(klab_swin_cpb_table_bwd(blk_dbtab, q.btab, e->swin_coords[st], q.hidden, W[ix.c2w], blk_dtable, G(ix.c0w), G(ix.c0b), G(ix.c2w),
                                    e->swin_ntab[st], q.H, 512, c.ws()));
       } else {
-        RC((int)hipMemsetAsync(e->sdbias, 0, (size_t)q.H * n * n * 4, c.s));
-        a.dbias = e->sdbias;
+        a.dbias = blk_dbias;
         RC(klab_swin_attn_bwd(&a, c.ws()));
-        RC(klab_swin_cpb_bias_bwd(e->sdbias, q.bias, e->swin_index[st], e->swin_coords[st], q.hidden, W[ix.c0w], W[ix.c2w], e->sdtable,
-                                  G(ix.c0w), G(ix.c0b), G(ix.c2w), e->swin_ntab[st], n, q.H, 512, c.ws()));
+        RC(klab_swin_cpb_bias_bwd_pz(blk_dbias, q.bias, e->swin_index[st], e->swin_coords[st], q.hidden, W[ix.c0w], W[ix.c2w], blk_dtable,
+                                     G(ix.c0w), G(ix.c0b), G(ix.c2w), e->swin_ntab[st], n, q.H, 512, 1, c.ws()));
       }
       if (side_on) {  // everything the block's weight gradients read exists now: release them to the side stream
         RC(side_after_main(c));

@@ -134,6 +134,7 @@ ENGINE_SIGS = {
     "klab_engine_buffer": ([C.c_void_p, C.c_char_p, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_int)], C.c_void_p),
     "klab_gelu_fwd": ([C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_void_p], C.c_int),
     "klab_swin_cpb_bias_bwd": ([C.c_void_p] * 11 + [C.c_int] * 4 + [C.c_void_p], C.c_int),
+    "klab_swin_cpb_bias_bwd_pz": ([C.c_void_p] * 11 + [C.c_int] * 5 + [C.c_void_p], C.c_int),
 }
 _sigs_installed = False
 
