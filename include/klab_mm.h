@@ -292,8 +292,10 @@ int klab_embed_bwd(const long long* ids, int shift_right, int L, int start_id, i
 int klab_relbias_fwd(const float* table, const int* bucket, float* bias, int heads, int Lq, int Lk, void* stream);
 int klab_relbias_bwd(const float* dbias, const int* bucket, float* dtable, int heads, int Lq, int Lk, int nbuckets,
                      void* stream);
-/* cross-entropy over logits [rows, V] (HF/t5:1050-1054); with write_grad the logits are replaced in
- * place by d loss / d logits = (softmax - onehot) / n_valid.  loss_row [rows], inv_n [1], loss [1]. */
+/* cross-entropy over logits [rows, V] (HF/t5:1050-1054); with write_grad (bit 0) the logits are replaced in
+ * place by d loss / d logits = (softmax - onehot) / n_valid.  loss_row [rows], inv_n [1], loss [1].
+ * write_grad bit 1: inv_n was already produced by klab_ce_count for the same labels (saves the counting launch). */
+int klab_ce_count(const long long* labels, int rows, float* inv_n, void* stream);
 int klab_ce_fwd(void* logits, long ld, int dtype, const long long* labels, int rows, int V, float* inv_n, float* loss_row,
                 float* loss, int write_grad, void* stream);
 int klab_im2col_patch(const float* pixels, void* out, int dtype, int B, int Cin, int Himg, int P, void* stream);

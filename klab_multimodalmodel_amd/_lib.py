@@ -96,6 +96,7 @@ SIGNATURES = {
     "klab_relbias_fwd": [vp, vp, vp, i32, i32, i32, vp],
     "klab_relbias_bwd": [vp, vp, vp, i32, i32, i32, i32, vp],
     "klab_ce_fwd": [vp, i64, i32, vp, i32, i32, vp, vp, vp, i32, vp],
+    "klab_ce_count": [vp, i32, vp, vp],
     "klab_im2col_patch": [vp, vp, i32, i32, i32, i32, i32, vp],
     "klab_im2col_patch_ld": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "klab_merge_gather": [vp, vp, i32, i32, i32, i32, vp],

@@ -164,6 +164,9 @@ struct klab_engine {
   bool dbias_zeroed[2] = {false, false};  // [decoder stack, encoder stack]
   bool denc_in_dxn = false;      // segment 0 left d(encoder output) in dxn, where segment 1's stack reads it
   float* loss_out = nullptr;     // one-shot destination of the next forward's loss (klab_engine_set_loss_out)
+  bool bias_ready[3] = {false, false, false};  // [stack id]: the stack's position bias was computed ahead of it, on the side stream
+  bool dec_embed_ready = false;   // ... and the decoder's input embedding
+  bool inv_n_ready = false;       // ... and 1 / n_valid of the labels
   // stream capture is illegal on the legacy default stream (where PyTorch runs unless told otherwise): in graph mode
   // calls arriving on stream 0 are executed on this engine-owned stream, fenced in and out with events
   hipStream_t own = nullptr; hipEvent_t ev_in = nullptr, ev_out = nullptr;
@@ -747,7 +750,8 @@ int t5_stack_forward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Par
   const int d = cfg.d_model, H = cfg.n_heads, dk = cfg.d_kv, inner = H * dk, ff = cfg.d_ff;
   const int M = s.M, Lq = s.Lseq;
   const int relb = L[0].relb;
-  RC(klab_relbias_fwd(W[relb], s.bucket, s.bias, H, Lq, Lq, c.ws()));
+  if (c.e->bias_ready[stack_id]) c.e->bias_ready[stack_id] = false;  // computed ahead, beside the Swin tower (forward_part_a)
+  else RC(klab_relbias_fwd(W[relb], s.bucket, s.bias, H, Lq, Lq, c.ws()));
   int j = 0;
   for (size_t i = 0; i < L.size(); ++i) {
     const T5LayerIdx& l = L[i];
@@ -1329,6 +1333,7 @@ extern "C" int klab_engine_bind(klab_engine* e, int B, int Ls, int Lt, void* wor
   }
   e->frozen_valid = false;
   e->seg1_zeroed = e->dbias_zeroed[0] = e->dbias_zeroed[1] = e->denc_in_dxn = false;  // (hand-offs between backward segments of the OLD binding)
+  e->bias_ready[0] = e->bias_ready[1] = e->bias_ready[2] = e->dec_embed_ready = e->inv_n_ready = false;
   e->loss_out = nullptr;
   if (e->pe_kp != e->pe_k0)  // the padding columns of the patch-embedding weight rows: written here, never again
     RC((int)hipMemsetAsync((char*)e->warena + (size_t)e->P[0][e->si.pew].warena_off * e->es, 0,
@@ -1537,6 +1542,21 @@ int forward_part_a(klab_engine* e, hipStream_t stream, float p, bool refresh_fro
   RC((int)hipStreamWaitEvent(e->side, e->ev_fork, 0));
   {
     Ctx cs{e, e->side, e->cfg.dtype, e->es};
+    // Small kernels that depend on nothing but the inputs and the weights run here, ahead of the language encoder and off the
+    // main chain (ev_join covers them): the position biases of the encoder and decoder stacks and the decoder's input embedding
+    // (5 launches of 4-6 us).  KLAB_EARLY_SMALL=0: where they were.
+    static const bool early = [] { const char* v = getenv("KLAB_EARLY_SMALL"); return !v || atoi(v) != 0; }();
+    if (early && !e->use_graph) {
+      const int H = cfg.main.n_heads;
+      RC(klab_relbias_fwd(e->W[2][e->mi.enc[0].relb], e->enc.bucket, e->enc.bias, H, e->enc.Lseq, e->enc.Lseq, cs.ws()));
+      RC(klab_relbias_fwd(e->W[2][e->mi.dec[0].relb], e->dec.bucket, e->dec.bias, H, e->dec.Lseq, e->dec.Lseq, cs.ws()));
+      e->bias_ready[STACK_ENC] = e->bias_ready[STACK_DEC] = true;
+      RC(klab_embed_fwd(tgt_ids, 1, e->Lt, cfg.main.start_id, cfg.main.pad_id, e->W[2][e->mi.shared], cfg.main.vocab, e->dec.h[0], B * e->Lt, d, p,
+                        e->seed_dev, tag_of(STACK_DEC, 0, SITE_IN), e->err_dev, cs.ws()));
+      e->dec_embed_ready = true;
+      RC(klab_ce_count(tgt_ids, B * e->Lt, e->inv_n, cs.ws()));  // 1 / n_valid of the labels: klab_ce_fwd then skips its counting launch
+      e->inv_n_ready = true;
+    }
     RC(klab_embed_fwd(src_ids, 0, e->Ls, 0, 0, e->W[1][e->li.shared], cfg.lang.vocab, e->lang.h[0], B * e->Ls, d, 0.f, nullptr, 0, e->err_dev,
                       cs.ws()));
     RC(t5_stack_forward(cs, cfg.lang, e->P[1], e->W[1], e->li.enc, e->li.enc_final, e->lang, false, STACK_LANG, 0.f, B, nullptr, 0, 0,
@@ -1550,8 +1570,9 @@ int forward_part_a(klab_engine* e, hipStream_t stream, float p, bool refresh_fro
   }
   // 5. decoder: shift_right + embedding (HF/t5:1026-1028), cross K/V of all layers in one GEMM, stack
   const int inner = cfg.main.n_heads * cfg.main.d_kv, nld = cfg.main.n_dec_layers;
-  RC(klab_embed_fwd(tgt_ids, 1, e->Lt, cfg.main.start_id, cfg.main.pad_id, e->W[2][e->mi.shared], cfg.main.vocab, e->dec.h[0], B * e->Lt, d, p,
-                    e->seed_dev, tag_of(STACK_DEC, 0, SITE_IN), e->err_dev, c.ws()));
+  if (e->dec_embed_ready) e->dec_embed_ready = false;
+  else RC(klab_embed_fwd(tgt_ids, 1, e->Lt, cfg.main.start_id, cfg.main.pad_id, e->W[2][e->mi.shared], cfg.main.vocab, e->dec.h[0], B * e->Lt, d, p,
+                         e->seed_dev, tag_of(STACK_DEC, 0, SITE_IN), e->err_dev, c.ws()));
   if (!encoder_current)
     RC(linear_fwd(c, e->enc.out_t, B * e->Le, d, e->kvall_w_off, nld * 2 * inner, e->kv_all, (long)nld * 2 * inner, c.dt));
   RC(t5_stack_forward(c, cfg.main, e->P[2], e->W[2], e->mi.dec, e->mi.dec_final, e->dec, true, STACK_DEC, p, B, e->kv_all, e->Le,
@@ -1660,10 +1681,12 @@ extern "C" int klab_engine_forward(klab_engine* e, const float* pixels, const lo
       if (klab::tl_launch_probe.a) klab::tl_launch_probe.a = nullptr;  // (a launch path without the hook, e.g. fp8: not recorded)
       else pr.flops[pr.n++] = 2.0 * Md * (double)V * d;
     }
+    const bool counted = e->inv_n_ready && !e->use_graph;
+    e->inv_n_ready = false;
     float* loss_dst = e->loss_out && !e->use_graph ? e->loss_out : e->loss;  // (replayed graphs write the fixed address)
     e->loss_out = nullptr;
     RC(run_graphed(e, want_grad ? 3 : 2, c.s, [&]() {
-      return klab_ce_fwd(e->logits, V, c.dt, e->tgt_buf, Md, V, e->inv_n, e->loss_row, loss_dst, want_grad, c.ws());
+      return klab_ce_fwd(e->logits, V, c.dt, e->tgt_buf, Md, V, e->inv_n, e->loss_row, loss_dst, (want_grad ? 1 : 0) | (counted ? 2 : 0), c.ws());
     }));
   }
   return leave_stream(e, (hipStream_t)stream, xs);

@@ -589,14 +589,26 @@ extern "C" int klab_relbias_bwd(const float* dbias, const int* bucket, float* dt
   return KLAB_OK;
 }
 
+// inv_n[0] = 1 / (number of labels != -100): the first launch of klab_ce_fwd on its own, for callers that know the labels long before
+// the logits exist (the engine runs it beside the Swin tower and passes write_grad | 2)
+extern "C" int klab_ce_count(const long long* labels, int rows, float* inv_n, void* stream) {
+  if (!labels || !inv_n || rows <= 0) return KLAB_ERR_BADARG;
+  hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, labels, rows, inv_n);
+  KLAB_LAUNCH_CHECK();
+  return KLAB_OK;
+}
+
 extern "C" int klab_ce_fwd(void* logits, long ld, int dtype, const long long* labels, int rows, int V, float* inv_n, float* loss_row,
                            float* loss, int write_grad, void* stream) {
   if (!logits || !labels || !inv_n || !loss_row || !loss) return KLAB_ERR_BADARG;
   const int vec = dtype == KLAB_BF16 ? 8 : 4;
   if (V % vec || ld % vec) return KLAB_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(256), 0, s, labels, rows, inv_n);
-  KLAB_LAUNCH_CHECK();
+  if (!(write_grad & 2)) {  // bit 1: inv_n already holds 1 / n_valid of these labels (klab_ce_count ran ahead of the logits)
+    hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(256), 0, s, labels, rows, inv_n);
+    KLAB_LAUNCH_CHECK();
+  }
+  write_grad &= 1;
   static const bool onepass = [] { const char* e = getenv("KLAB_CE_ONEPASS"); return !e || atoi(e) != 0; }();
   if (dtype == KLAB_BF16 && onepass && V <= 256 * 8 * 16 && V > 256 * 8 * 8)
     hipLaunchKernelGGL((ce_fwd_onepass_kernel<bf16_t, 16>), dim3(rows), dim3(256), 0, s, (bf16_t*)logits, ld, labels, V, inv_n, loss_row, write_grad);
