@@ -378,7 +378,7 @@ def main():
         # durations around each launch on the stream it runs on; algorithmic FLOPs = 2*M*N*K per product
         rl = []
         names = ["klab_lmhead_areg_gemm / klab_lmhead_gemm<bf16> (LM-head logits GEMM [B*Lt, 32128] x d_model; A-stationary form at d_model 512)",
-                 "gemm_glds_grouped_tn_kernel (one grouped launch = all weight-gradient GEMMs of one T5 layer, side stream)"]
+                 "mm8p_grouped_tn_kernel / gemm_glds_grouped_tn_kernel (one grouped launch = the weight-gradient GEMMs of 2-3 T5 layers on 256 x 256 tiles, or of one layer on 128 x 128; side stream)"]
         for ch, (n, tot_ms, fl) in enumerate(probes):
             if n <= 0 or tot_ms <= 0:
                 continue

@@ -847,9 +847,28 @@ int main_after_side(const Ctx& c) {
 struct PendingWgrad { const void* dy; long lddy; const void* x; long ldx; int M, N, K; float* dw; };
 struct WgradQueue {
   std::vector<PendingWgrad> q;
+  int layers = 0;  // flush calls (= layers) the queue spans
   void push(const void* dy, long lddy, const void* x, long ldx, int M, int N, int K, float* dw) { q.push_back({dy, lddy, x, ldx, M, N, K, dw}); }
-  int flush(const Ctx& c) {
-    if (q.empty()) return 0;
+  // KLAB_WGRAD_GROUP_TILES=T: keep queueing across layers until the queued products make up T output tiles of 256 x 256 (or the
+  // stack ends), then release them in ONE grid of large tiles (mm8p.hip): half the operand bytes of the 128-wide grouping.  One
+  // layer's products are 48-56 such tiles -- a fifth of the chip, which is why per-layer large tiles lost (KLAB_WGRAD_P8, 6.41 vs
+  // 6.18 ms) -- two decoder layers (112) or three encoder layers (144) measured best: same box, three rounds, T = 0 / 90 / 110 / 150:
+  // 6.043 / 6.007 / 5.983 / 6.028 ms per step.  Default 110; 0 = one 128-wide grouped launch per layer (round 2's form).  A layer
+  // that reaches T on its own (T5-large: 200+ tiles) is released at once on the 128-wide kernel as before: large tiles only for
+  // lists that span layers (per-layer large tiles cost configs[4] 20 ms per step).
+  int flush(const Ctx& c, bool force = true, bool* launched = nullptr) {
+    if (launched) *launched = false;
+    ++layers;
+    if (q.empty()) { layers = 0; return 0; }
+    static const int group_tiles = [] { const char* v = getenv("KLAB_WGRAD_GROUP_TILES"); return v ? atoi(v) : 110; }();
+    if (group_tiles > 0 && !force && q.size() + 8 <= 32) {
+      long t = 0;
+      for (const PendingWgrad& w : q) t += (long)((w.N + 255) / 256) * ((w.K + 255) / 256);
+      if (t < group_tiles) return 0;
+    }
+    if (launched) *launched = true;
+    const bool large = group_tiles > 0 && layers >= 2;  // a list that spans layers goes to the 256 x 256 grouped kernel
+    layers = 0;
     // timing diagnostics only (results are wrong / unoverlapped): KLAB_DIAG_WGRAD=skip drops the layer's weight gradients,
     // =main runs them on the main stream behind the layer's chain instead of beside it
     static const int diag = [] { const char* v = getenv("KLAB_DIAG_WGRAD"); return !v ? 0 : (v[0] == 's' ? 1 : (v[0] == 'm' ? 2 : 0)); }();
@@ -867,7 +886,10 @@ struct WgradQueue {
     const bool probe = c.e->probe_on && pr.n < (int)pr.a.size();
     // (the grouped launch itself carries the events as its start / stop events: no extra packets on the stream)
     if (probe) { klab::tl_launch_probe.a = pr.a[pr.n]; klab::tl_launch_probe.b = pr.b[pr.n]; }
-    RC(klab_gemm_grouped(gs.data(), (int)gs.size(), cs.ws()));
+    klab::tl_grouped_large_tiles = large;
+    const int grc = klab_gemm_grouped(gs.data(), (int)gs.size(), cs.ws());
+    klab::tl_grouped_large_tiles = false;
+    RC(grc);
     if (probe) {
       if (klab::tl_launch_probe.a) klab::tl_launch_probe.a = nullptr;  // no grouped launch happened (members went through klab_gemm)
       else {
@@ -919,6 +941,7 @@ int t5_stack_backward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Pa
   void* dy = next_dy();  // masked, compute-dtype gradient of the current sub-layer's GEMM output
   RC(rms_bwd(e->dxn, s.h[j], W[final_ln], s.rstd_f, nullptr, dh_cur, dy, final_ln, p, tag_of(stack_id, 0, SITE_FINAL), p,
              tag_of(stack_id, (int)L.size() - 1, SITE_FFN_OUT)));
+  std::vector<int> pending_buckets;  // layers whose weight gradients are queued but not yet launched
   for (int i = (int)L.size() - 1; i >= 0; --i) {
     const T5LayerIdx& l = L[i];
     T5LayerBufs& b = s.L[i];
@@ -995,13 +1018,17 @@ int t5_stack_backward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Pa
                  first ? 0u : tag_of(stack_id, i - 1, SITE_FFN_OUT)));
       float* t = dh_cur; dh_cur = dh_oth; dh_oth = t;
     }
-    RC(wq.flush(c));  // this layer's weight gradients: one event, then they overlap the next layer's chain
-    {  // the layer's bucket of the flat gradient buffer is final behind this point of the side stream
-      const int seg = dec ? 0 : 1, bi = (int)L.size() - 1 - i;
-      if (e->bucket_events_on && Gflat == e->G[2] && !e->use_graph && bi < (int)e->bucket_ev[seg].size()) {
-        RC((int)hipEventRecord(e->bucket_ev[seg][bi], e->side));
-        if (i == 0) e->bucket_ev_live[seg] = true;
-      }
+    bool launched = false;
+    RC(wq.flush(c, /*force=*/i == 0, &launched));  // this layer's weight gradients: one event, then they overlap the next layer's chain
+    pending_buckets.push_back((int)L.size() - 1 - i);
+    if (launched) {  // the buckets of every layer released so far are final behind this point of the side stream
+      const int seg = dec ? 0 : 1;
+      for (int bi : pending_buckets)
+        if (e->bucket_events_on && Gflat == e->G[2] && !e->use_graph && bi < (int)e->bucket_ev[seg].size())
+          RC((int)hipEventRecord(e->bucket_ev[seg][bi], e->side));
+      pending_buckets.clear();
+      if (i == 0 && e->bucket_events_on && Gflat == e->G[2] && !e->use_graph && (int)L.size() - 1 < (int)e->bucket_ev[seg].size())
+        e->bucket_ev_live[seg] = true;
     }
   }
   if (part_ok && rms_calls) {

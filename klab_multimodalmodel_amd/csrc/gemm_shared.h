@@ -25,6 +25,9 @@ inline void probed_launch(K kern, dim3 grid, dim3 block, size_t lds, hipStream_t
   }
 }
 
+// set by the engine around a klab_gemm_grouped call whose list spans several layers: take the 256 x 256 grouped kernel (mm8p.hip)
+inline thread_local bool tl_grouped_large_tiles = false;
+
 struct GemmP {
   int M, N, K;
   const void* A; long lda; int a_kmajor;

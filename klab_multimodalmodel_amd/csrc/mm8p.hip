@@ -452,11 +452,12 @@ __global__ __launch_bounds__(512) void mm8p_kernel(GemmP p) { mm8p_body<AK, BKM,
 // workgroup: no split-K, no atomics, half the operand traffic of the 128 x 128 split-K form (gemm.hip's grouped kernel), and a
 // layer's gradients occupy ~50 CUs instead of all 256 -- they run on a side stream beside the activation-gradient chain.
 struct Group8Entry { const void* A; long lda; const void* B; long ldb; float* C; long ldc; int M, N, K, start; float alpha; };
-struct Group8P { Group8Entry e[8]; int n; };
+constexpr int GROUP_MAX = 32;  // (several layers' products in one grid: KLAB_WGRAD_GROUP_TILES)
+struct Group8P { Group8Entry e[GROUP_MAX]; int n; };
 __global__ __launch_bounds__(512) void mm8p_grouped_tn_kernel(Group8P g) {
   int i = 0;
 #pragma unroll
-  for (int k = 1; k < 8; ++k)
+  for (int k = 1; k < GROUP_MAX; ++k)
     if (k < g.n && (int)blockIdx.x >= g.e[k].start) i = k;
   const Group8Entry& e = g.e[i];
   GemmP p;
@@ -478,8 +479,8 @@ __global__ __launch_bounds__(512) void mm8p_grouped_tn_kernel(Group8P g) {
 // 128 x 128 split-K grouped kernel for the whole list)
 int mm8p_grouped_try(const klab_gemm_args* list, int n, hipStream_t s) {
   using namespace p8;
-  static const int mode = [] { const char* e = getenv("KLAB_WGRAD_P8"); return e ? atoi(e) : 0; }();  // 0: off (default), 1: on
-  if (mode == 0 || n <= 0 || n > 8) return KLAB_ERR_UNSUPPORTED;
+  static const int mode = [] { const char* e = getenv("KLAB_WGRAD_P8"); return e ? atoi(e) : 0; }();  // 1: every grouped list (experiment)
+  if ((mode == 0 && !tl_grouped_large_tiles) || n <= 0 || n > GROUP_MAX) return KLAB_ERR_UNSUPPORTED;
   Group8P g;
   g.n = 0;
   int blocks = 0;

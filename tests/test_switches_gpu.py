@@ -18,6 +18,7 @@ SWITCHES = [
     {"KLAB_LMHEAD_AREG": "0"},        # LM-head logits on the 128 x 128 tiled kernel
     {"KLAB_T5_ATTN_FUSED": "0"},      # rms-norm + projection + attention as three launches
     {"KLAB_SWIN_FUSED_LIN_LN": "0", "KLAB_SWIN_FUSED_EMBED": "0"},  # frozen tower: GEMM + LayerNorm, im2col + GEMM + LayerNorm
+    {"KLAB_WGRAD_GROUP_TILES": "0"},  # weight gradients: one 128-wide grouped launch per layer instead of 256-wide tiles over 2-3 layers
     {"KLAB_GEMM_P8": "0"},            # no 256 x 256 tiles (LM-head input gradient on 128 x 128 tiles, split K)
 ]
 

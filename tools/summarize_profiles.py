@@ -80,7 +80,7 @@ def main():
         for o in out:
             w.writerow({c: v for c, v in o.items() if c != "_full"})
     traffic = {}
-    for key, pat in (("lmhead", "klab_lmhead_"), ("grouped_wgrad", "gemm_glds_grouped_tn_kernel")):
+    for key, pat in (("lmhead", "klab_lmhead_"), ("grouped_wgrad", "grouped_tn_kernel")):
         for o in out:
             if pat in o["_full"] and o["hbm_mb_per_launch"] is not None:
                 traffic[key] = {"kernel": o["kernel"], "hbm_bytes_per_launch": int(o["hbm_mb_per_launch"] * 1e6), "fetch_kb_raw": o["fetch_kb_raw"],
