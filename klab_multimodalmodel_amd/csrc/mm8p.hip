@@ -500,7 +500,7 @@ int mm8p_grouped_try(const klab_gemm_args* list, int n, hipStream_t s) {
   const size_t lds = LDS_RING > epi_bytes ? LDS_RING : epi_bytes;
   int rc = ensure_dyn_lds(reinterpret_cast<const void*>(mm8p_grouped_tn_kernel), lds);
   if (rc) return rc;
-  hipLaunchKernelGGL(mm8p_grouped_tn_kernel, dim3((unsigned)blocks), dim3(NT), lds, s, g);
+  probed_launch(mm8p_grouped_tn_kernel, dim3((unsigned)blocks), dim3(NT), lds, s, g);  // (carries the engine's probe events, if armed)
   KLAB_LAUNCH_CHECK();
   return KLAB_OK;
 }
