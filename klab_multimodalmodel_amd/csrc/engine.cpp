@@ -1879,6 +1879,9 @@ static int backward_segment(klab_engine* e, int segment, const float* dloss_dev,
     {  // d shared [V,d] = dlogits^T @ dec_out  (first of the tied weight's three contributors)
       klab_gemm_args g = G0(cs, V, d, Md, e->logits, V, 0, e->dec.out_t, d, 0, Gm + e->P[2][e->mi.shared].grad_off, d, KLAB_F32);
       g.alpha = alpha; g.alpha_dev = dloss_dev; g.accumulate = 1; g.atomic_ok = 1;
+      // KLAB_LMHEAD_WGRAD_P8=1 (experiment): 256 x 256 tiles (252 of them, half the operand bytes of the 1004 tiles of 128 x 128)
+      static const bool wg_p8 = [] { const char* v = getenv("KLAB_LMHEAD_WGRAD_P8"); return v && atoi(v) != 0; }();
+      if (wg_p8) g.name_tag = 2;
       RC(klab_gemm(&g, cs.ws()));
     }
     float* dh0 = nullptr;
