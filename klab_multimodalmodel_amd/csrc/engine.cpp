@@ -167,6 +167,7 @@ struct klab_engine {
   bool bias_ready[3] = {false, false, false};  // [stack id]: the stack's position bias was computed ahead of it, on the side stream
   bool dec_embed_ready = false;   // ... and the decoder's input embedding
   bool inv_n_ready = false;       // ... and 1 / n_valid of the labels
+  bool kv_wgrad_done = false;     // the cross k|v weight gradients went out with the decoder layers' groups
   // stream capture is illegal on the legacy default stream (where PyTorch runs unless told otherwise): in graph mode
   // calls arriving on stream 0 are executed on this engine-owned stream, fenced in and out with events
   hipStream_t own = nullptr; hipEvent_t ev_in = nullptr, ev_out = nullptr;
@@ -849,25 +850,16 @@ struct WgradQueue {
   std::vector<PendingWgrad> q;
   int layers = 0;  // flush calls (= layers) the queue spans
   void push(const void* dy, long lddy, const void* x, long ldx, int M, int N, int K, float* dw) { q.push_back({dy, lddy, x, ldx, M, N, K, dw}); }
-  // KLAB_WGRAD_GROUP_TILES=T: keep queueing across layers until the queued products make up T output tiles of 256 x 256 (or the
-  // stack ends), then release them in ONE grid of large tiles (mm8p.hip): half the operand bytes of the 128-wide grouping.  One
-  // layer's products are 48-56 such tiles -- a fifth of the chip, which is why per-layer large tiles lost (KLAB_WGRAD_P8, 6.41 vs
-  // 6.18 ms) -- two decoder layers (112) or three encoder layers (144) measured best: same box, three rounds, T = 0 / 90 / 110 / 150:
-  // 6.043 / 6.007 / 5.983 / 6.028 ms per step.  Default 110; 0 = one 128-wide grouped launch per layer (round 2's form).  A layer
-  // that reaches T on its own (T5-large: 200+ tiles) is released at once on the 128-wide kernel as before: large tiles only for
-  // lists that span layers (per-layer large tiles cost configs[4] 20 ms per step).
-  int flush(const Ctx& c, bool force = true, bool* launched = nullptr) {
+  // Called once per layer.  now == false: keep the layer's products queued (the caller's plan releases them with a later layer's);
+  // now == true: release everything queued in ONE grouped launch -- on 256 x 256 tiles (mm8p.hip: half the operand bytes of the
+  // 128-wide grouping) when the list spans two layers or more, on the 128-wide kernel when it is one layer's.
+  int flush(const Ctx& c, bool now = true, bool* launched = nullptr) {
     if (launched) *launched = false;
     ++layers;
     if (q.empty()) { layers = 0; return 0; }
-    static const int group_tiles = [] { const char* v = getenv("KLAB_WGRAD_GROUP_TILES"); return v ? atoi(v) : 110; }();
-    if (group_tiles > 0 && !force && q.size() + 8 <= 32) {
-      long t = 0;
-      for (const PendingWgrad& w : q) t += (long)((w.N + 255) / 256) * ((w.K + 255) / 256);
-      if (t < group_tiles) return 0;
-    }
+    if (!now && q.size() + 8 <= 32) return 0;
     if (launched) *launched = true;
-    const bool large = group_tiles > 0 && layers >= 2;  // a list that spans layers goes to the 256 x 256 grouped kernel
+    const bool large = layers >= 2;  // a list that spans layers goes to the 256 x 256 grouped kernel
     layers = 0;
     // timing diagnostics only (results are wrong / unoverlapped): KLAB_DIAG_WGRAD=skip drops the layer's weight gradients,
     // =main runs them on the main stream behind the layer's chain instead of beside it
@@ -942,6 +934,34 @@ int t5_stack_backward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Pa
   RC(rms_bwd(e->dxn, s.h[j], W[final_ln], s.rstd_f, nullptr, dh_cur, dy, final_ln, p, tag_of(stack_id, 0, SITE_FINAL), p,
              tag_of(stack_id, (int)L.size() - 1, SITE_FFN_OUT)));
   std::vector<int> pending_buckets;  // layers whose weight gradients are queued but not yet launched
+  // Release plan of the weight gradients (KLAB_WGRAD_GROUP_TILES = T, default 90; 0 = one 128-wide grouped launch per layer, round
+  // 2's form).  One T5-small layer's products are 48-64 tiles of 256 x 256 -- a fifth of the chip, and a large tile takes ~100 us
+  // whatever the grid, which is why PER-LAYER large tiles lost (KLAB_WGRAD_P8: 6.41 vs 6.18 ms).  So the layers of a stack except
+  // its last are released in groups of >= T tiles (T5-small: decoder 3 + 2 layers, encoder 3 + 2; same box, three rounds, T = 0 / 90
+  // / 110 (encoder 5 in one group) / 200: 5.990 / 5.855 / 5.880 / 5.982 ms per step), and the LAST layer alone on the
+  // 128-wide kernel: its launch is the tail the segment's end waits for, and 70 us of tail hide behind the main chain's own last
+  // kernels where a 180-us group does not.  A layer that reaches T on its own (T5-base / large) keeps the per-layer form.
+  const int Ln = (int)L.size();
+  std::vector<char> flush_at(Ln, 1);
+  static const int group_tiles = [] { const char* v = getenv("KLAB_WGRAD_GROUP_TILES"); return v ? atoi(v) : 90; }();
+  static const bool kv_per_layer = [] { const char* v = getenv("KLAB_KV_WGRAD_PER_LAYER"); return !v || atoi(v) != 0; }();
+  const bool kv_in_queue = dec && dkv_all && kv_per_layer && Gflat == e->G[2] && !e->use_graph && e->kvall_g_off >= 0;
+  if (group_tiles > 0 && Ln >= 3 && Gflat == e->G[2] && !e->use_graph) {
+    auto T2 = [](int n, int k) { return (long)((n + 255) / 256) * ((k + 255) / 256); };
+    const long tl = T2(d, ff) + T2(ff, d) + T2(d, inner) + T2(3 * inner, d) + (dec ? T2(d, inner) + T2(inner, d) + (kv_in_queue ? T2(2 * inner, d) : 0) : 0);
+    const int per_group = (int)((group_tiles + tl - 1) / tl), per_layer = dec ? 7 : 4;
+    if (per_group >= 2) {
+      const int body = Ln - 1;
+      int ng = body / per_group;
+      if (ng < 1) ng = 1;
+      if (((body + ng - 1) / ng) * per_layer <= 32) {  // (a grouped launch takes 32 products)
+        std::fill(flush_at.begin(), flush_at.end(), 0);
+        int i = Ln - 1;
+        for (int gi = 0; gi < ng; ++gi) { i -= body / ng + (gi < body % ng ? 1 : 0); flush_at[i + 1] = 1; }
+        flush_at[0] = 1;
+      }
+    }
+  }
   for (int i = (int)L.size() - 1; i >= 0; --i) {
     const T5LayerIdx& l = L[i];
     T5LayerBufs& b = s.L[i];
@@ -979,6 +999,10 @@ int t5_stack_backward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Pa
       a.dk_out = eoff(c, dkv_all, (long)i * 2 * inner); a.lddk = kv_ld;
       a.dv = eoff(c, dkv_all, (long)i * 2 * inner + inner); a.lddv = kv_ld;
       RC(klab_t5_attn_bwd(&a, c.ws()));
+      if (kv_in_queue) {  // this layer's k | v projection: its slice of d(k|v) is final, the product joins the layer's group
+        wq.push(eoff(c, dkv_all, (long)i * 2 * inner), kv_ld, e->enc.out_t, d, B * Lkv, 2 * inner, d, Gflat + e->kvall_g_off + (long)i * 2 * inner * d);
+        e->kv_wgrad_done = true;
+      }
       wq.push(dqc, inner, b.xn2, d, M, inner, d, G(l.cq));
       RC(linear_dgrad(c, dqc, inner, M, inner, P[l.cq].warena_off, d, e->dxn, KLAB_F32));
       dy = next_dy();
@@ -1019,7 +1043,7 @@ int t5_stack_backward(const Ctx& c, const klab_t5_cfg& cfg, const std::vector<Pa
       float* t = dh_cur; dh_cur = dh_oth; dh_oth = t;
     }
     bool launched = false;
-    RC(wq.flush(c, /*force=*/i == 0, &launched));  // this layer's weight gradients: one event, then they overlap the next layer's chain
+    RC(wq.flush(c, flush_at[i] != 0, &launched));  // (one main->side event per release; the launch overlaps the following layers' chain)
     pending_buckets.push_back((int)L.size() - 1 - i);
     if (launched) {  // the buckets of every layer released so far are final behind this point of the side stream
       const int seg = dec ? 0 : 1;
@@ -1360,7 +1384,7 @@ extern "C" int klab_engine_bind(klab_engine* e, int B, int Ls, int Lt, void* wor
   }
   e->frozen_valid = false;
   e->seg1_zeroed = e->dbias_zeroed[0] = e->dbias_zeroed[1] = e->denc_in_dxn = false;  // (hand-offs between backward segments of the OLD binding)
-  e->bias_ready[0] = e->bias_ready[1] = e->bias_ready[2] = e->dec_embed_ready = e->inv_n_ready = false;
+  e->bias_ready[0] = e->bias_ready[1] = e->bias_ready[2] = e->dec_embed_ready = e->inv_n_ready = e->kv_wgrad_done = false;
   e->loss_out = nullptr;
   if (e->pe_kp != e->pe_k0)  // the padding columns of the patch-embedding weight rows: written here, never again
     RC((int)hipMemsetAsync((char*)e->warena + (size_t)e->P[0][e->si.pew].warena_off * e->es, 0,
@@ -1894,7 +1918,8 @@ static int backward_segment(klab_engine* e, int segment, const float* dloss_dev,
                       e->seed_dev, tag_of(STACK_DEC, 0, SITE_IN), cs.ws()));
     // cross-attention K/V projections of all layers at once: weights (side) + d(encoder output) (main)
     const int Me = B * e->Le, Nkv = nld * 2 * inner;
-    RC(linear_wgrad(cs, e->dkv_all, Nkv, e->enc.out_t, d, Me, Nkv, d, Gm + e->kvall_g_off));
+    if (e->kv_wgrad_done) e->kv_wgrad_done = false;  // released layer by layer with the decoder's groups (t5_stack_backward)
+    else RC(linear_wgrad(cs, e->dkv_all, Nkv, e->enc.out_t, d, Me, Nkv, d, Gm + e->kvall_g_off));
     // d(encoder output) goes straight to dxn, where segment 1's stack reads d(final-norm output): no copy at the segment boundary
     e->denc_in_dxn = !e->use_graph;
     RC(linear_dgrad(c, e->dkv_all, Nkv, Me, Nkv, e->kvall_w_off, d, e->denc_in_dxn ? e->dxn : e->denc, KLAB_F32));
