@@ -70,11 +70,22 @@ __global__ __launch_bounds__(256) void cast_pack_kernel(const CastDesc* __restri
 // bf16/f32 copy the next forward's GEMMs read, written straight into the engine's weight arena (the separate cast pass
 // over the masters disappears).  m / v live in flat buffers laid out like the flat gradient buffer.
 struct AdamDesc { float* p; long goff; long aoff; long n4_prefix; };  // aoff < 0: no arena copy
-struct AdamHyper { float lr_over_bc1, beta1, beta2, eps, weight_decay, inv_sqrt_bc2; };
+struct AdamHyper { float lr_over_bc1, beta1, beta2, eps, weight_decay, inv_sqrt_bc2; int desc_in_lds; };
 
 template <typename T, int U = 4, bool NT = false>
-__global__ __launch_bounds__(256) void adam_step_kernel(const AdamDesc* __restrict__ d, int nd, long begin4, long total4, const float* __restrict__ grads,
+__global__ __launch_bounds__(256) void adam_step_kernel(const AdamDesc* __restrict__ dglob, int nd, long begin4, long total4, const float* __restrict__ grads,
                                                         float* __restrict__ m, float* __restrict__ v, T* __restrict__ arena, AdamHyper h) {
+  // The descriptor table (one entry per tensor: ~130 for T5-small) is searched once per thread and iteration -- eight DEPENDENT loads,
+  // then three more per vector for the tensor's addresses.  From global memory that chain (~1.5 us of L2 round trips) ran in front
+  // of every batch of streaming loads and kept the kernel at 4.5 TB/s; a copy in LDS makes it ~100 cycles per step.
+  constexpr int MAXD = 512;
+  __shared__ AdamDesc dsh[MAXD];
+  const bool in_lds = nd <= MAXD && h.desc_in_lds;
+  if (in_lds) {
+    for (int i = threadIdx.x; i < nd; i += blockDim.x) dsh[i] = dglob[i];
+    __syncthreads();
+  }
+  const AdamDesc* d = in_lds ? dsh : dglob;
   // vec4 indices [begin4, total4) of the descriptor table's prefix space (a sub-range = the tensors of one backward segment)
   for (long g0 = begin4 + ((long)blockIdx.x * U) * blockDim.x + threadIdx.x; g0 < total4; g0 += (long)gridDim.x * U * blockDim.x) {
     int lo = 0, hi = nd - 1;
@@ -528,7 +539,8 @@ extern "C" int klab_adam_step_range(const void* desc_dev, int ndesc, long begin4
   if (!desc_dev || ndesc <= 0 || !grads || !m || !v || !arena || bias_corr1 <= 0.f || bias_corr2 <= 0.f || begin4 < 0 || end4 < begin4)
     return KLAB_ERR_BADARG;
   if (end4 == begin4) return KLAB_OK;
-  AdamHyper h{lr / bias_corr1, beta1, beta2, eps, weight_decay, 1.f / sqrtf(bias_corr2)};
+  static const int desc_lds = [] { const char* e = getenv("KLAB_ADAM_DESC_LDS"); return !e || atoi(e) != 0 ? 1 : 0; }();
+  AdamHyper h{lr / bias_corr1, beta1, beta2, eps, weight_decay, 1.f / sqrtf(bias_corr2), desc_lds};
   hipStream_t s = (hipStream_t)stream;
   static const int cap = [] { const char* e = getenv("KLAB_ADAM_GRID"); return e ? atoi(e) : 1024; }();
   // non-temporal loads / stores: every byte is touched once per step (415 -> 397 us); an 8-deep unroll measured 1.5 ms (spills)
