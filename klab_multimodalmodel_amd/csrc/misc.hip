@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const AdamDesc* __restri
   // The descriptor table (one entry per tensor: ~130 for T5-small) is searched once per thread and iteration -- eight DEPENDENT loads,
   // then three more per vector for the tensor's addresses.  From global memory that chain (~1.5 us of L2 round trips) ran in front
   // of every batch of streaming loads and kept the kernel at 4.5 TB/s; a copy in LDS makes it ~100 cycles per step.
-  constexpr int MAXD = 512;
+  constexpr int MAXD = 1024;  // (T5-large: ~560 tensors; 32 KiB)
   __shared__ AdamDesc dsh[MAXD];
   const bool in_lds = nd <= MAXD && h.desc_in_lds;
   if (in_lds) {
