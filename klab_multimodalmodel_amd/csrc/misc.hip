@@ -32,7 +32,15 @@ int ensure_dyn_lds(const void* kernel, size_t bytes) {
 struct CastDesc { const float* src; long dst_off; long n4_prefix; };  // prefix in units of 4 elements
 
 template <typename T>
-__global__ __launch_bounds__(256) void cast_pack_kernel(const CastDesc* __restrict__ d, int nd, long total4, T* __restrict__ dst) {
+__global__ __launch_bounds__(256) void cast_pack_kernel(const CastDesc* __restrict__ dglob, int nd, long total4, T* __restrict__ dst) {
+  // the descriptor table in LDS: the search below is a chain of dependent loads (see adam_step_kernel)
+  constexpr int MAXD = 1024;
+  __shared__ CastDesc dsh[MAXD];
+  if (nd <= MAXD) {
+    for (int i = threadIdx.x; i < nd; i += blockDim.x) dsh[i] = dglob[i];
+    __syncthreads();
+  }
+  const CastDesc* d = nd <= MAXD ? dsh : dglob;
   // A thread converts U vec4's, blockDim apart (so every wave-instruction is a contiguous 1 KiB read), all U loads in
   // flight at once; the descriptor is found by ONE binary search per thread and then walked forward (a search per
   // vec4 was 7 dependent loads in front of every 16-byte read: 2.4 TB/s; tensors are far longer than U*256 vec4's).
